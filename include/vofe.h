@@ -1,0 +1,123 @@
+/*
+ * vofe.h -- C ABI of the MI355X (gfx950) visual-odometry feature front end.
+ *
+ * Drop-in boundary for the ONE hot path of DiaHidvegi/visual-odometry: the three OpenCV calls
+ * its Python reaches per frame.  Every entry point is `extern "C"`, takes plain pointers and
+ * sizes (device pointers unless a parameter is named h_*), returns 0 on success or a negative
+ * VOFE_E_* code, and never throws.  The message for the last failure on the calling thread is
+ * returned by vofe_last_error().
+ *
+ * Ownership: the caller owns every image / point / status / err buffer (device memory, e.g.
+ * torch.Tensor.data_ptr()); the library owns only the ctx workspace and vofe_pyr objects.
+ * Threading: a ctx is bound to one device and one stream and is not thread-safe; use one ctx
+ * per thread / GPU.  Launches are asynchronous on the ctx stream unless stated otherwise.
+ *
+ * There is no CPU fallback in this library: without a usable gfx950 device vofe_create fails.
+ */
+#ifndef VOFE_H
+#define VOFE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOFE_OK 0
+#define VOFE_E_ARG (-1)      /* cv2 would raise cv2.error (assert on arguments) */
+#define VOFE_E_HIP (-2)      /* a HIP runtime call failed */
+#define VOFE_E_UNSUPPORTED (-3)
+#define VOFE_E_NOMEM (-4)
+
+/* cv2 constants used by the reference (continuous.py:27-28, initialization.py:49-50) */
+#define VOFE_TERM_CRITERIA_COUNT 1
+#define VOFE_TERM_CRITERIA_EPS 2
+#define VOFE_OPTFLOW_USE_INITIAL_FLOW 4
+#define VOFE_OPTFLOW_LK_GET_MIN_EIGENVALS 8
+
+typedef struct vofe_ctx vofe_ctx;
+typedef struct vofe_pyr vofe_pyr;
+
+const char* vofe_last_error(void);
+int vofe_version(void);
+
+/* Bind a context to `device` and to an existing HIP stream (NULL = the default stream). */
+int vofe_create(int device, void* hip_stream, vofe_ctx** out);
+int vofe_destroy(vofe_ctx* ctx);
+int vofe_synchronize(vofe_ctx* ctx);
+
+/* ---- Gaussian pyramid + Scharr derivatives --------------------------------------------------
+ * Replaces cv::buildOpticalFlowPyramid + cv::calcScharrDeriv, which cv2.calcOpticalFlowPyrLK runs
+ * internally at reference continuous.py:145-146, 150-151 and initialization.py:51-52.
+ * A vofe_pyr holds `slots` images of identical geometry (each slot: all levels, REFLECT_101
+ * padded by the window, plus zero-padded int16x2 derivative planes when with_deriv != 0).
+ * The number of levels follows OpenCV: it stops early when the next level would not exceed the
+ * window. */
+int vofe_pyramid_create(vofe_ctx* ctx, int slots, int height, int width, int win_w, int win_h,
+                        int max_level, int with_deriv, vofe_pyr** out);
+int vofe_pyramid_free(vofe_ctx* ctx, vofe_pyr* pyr);
+/* Build `count` consecutive slots starting at slot0 from images d_img + i*img_stride (bytes),
+ * rows `pitch` bytes apart. */
+int vofe_pyramid_build(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, const uint8_t* d_img,
+                       int pitch, size_t img_stride);
+int vofe_pyramid_levels(const vofe_pyr* pyr);
+int vofe_pyramid_level_size(const vofe_pyr* pyr, int level, int* width, int* height);
+/* Synchronous copies of one level to host memory (parity tests): unpadded image (w*h bytes),
+ * unpadded derivative (w*h*2 int16, may be NULL), or the image with `pad_x`/`pad_y` border
+ * columns/rows ((w+2*pad_x)*(h+2*pad_y) bytes; pad_x <= win_w, pad_y <= win_h). */
+int vofe_pyramid_download(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int level,
+                          uint8_t* h_image, int16_t* h_deriv);
+int vofe_pyramid_download_padded(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int level,
+                                 int pad_x, int pad_y, uint8_t* h_image);
+
+/* ---- pyramidal Lucas-Kanade ------------------------------------------------------------------
+ * Replaces cv2.calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel,
+ * criteria, flags, minEigThreshold) as called at reference continuous.py:145-146, 150-151 and
+ * initialization.py:51-52.  prev/next pyramids must have the same geometry and window; maxLevel
+ * is the pyramids' level count - 1.  Point i reads slot prev_slot + idx and next_slot + idx with
+ * idx = d_img_idx ? d_img_idx[i] : 0, so one launch tracks a ragged batch of independent
+ * sequences.  d_prev_pts / d_next_pts are (n,2) f32 xy; d_next_pts is read only with
+ * VOFE_OPTFLOW_USE_INITIAL_FLOW.  d_status (n) u8, d_err (n) f32 (entries cv2 leaves
+ * uninitialised are written as 0). */
+int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
+                  int flags, double min_eig_thr);
+
+/* Replaces ContinuousVO._track_keypoints (reference continuous.py:131-164) in one launch:
+ * forward LK, backward LK from every forward output, status &= max|prev - back| < fb_thresh
+ * (the backward status is ignored, as at continuous.py:150,158).  Both pyramids need derivatives. */
+int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
+                  double min_eig_thr, float fb_thresh);
+
+/* ---- corner detection --------------------------------------------------------------------------
+ * vofe_corner_score replaces cv::cornerMinEigenVal / cv::cornerHarris (blockSize 3, Sobel
+ * aperture 3) that cv2.goodFeaturesToTrack runs at reference continuous.py:380-385 and
+ * initialization.py:41-42.  d_score is (batch, height, width) f32, contiguous. */
+int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
+                      int pitch, size_t img_stride, int block_size, int aperture, int harris,
+                      double k, float* d_score);
+
+/* Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
+ * useHarrisDetector, k) (reference continuous.py:380-385, initialization.py:41-42).
+ * d_corners_xy receives up to `capacity` (x,y) f32 pairs, strongest first; *h_n_out (host) the
+ * number of corners cv2 would return (0 == cv2 returning None), which may exceed capacity only
+ * when max_corners <= 0.  d_mask may be NULL (u8, height*width, contiguous).
+ * Synchronous: returns after the corner count is known. */
+int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
+              int max_corners, double quality, double min_distance, const uint8_t* d_mask,
+              int block_size, int aperture, int harris, double k, float* d_corners_xy,
+              int capacity, int* h_n_out);
+
+/* Batched variant: `batch` images of identical geometry; image b writes its corners to
+ * d_corners_xy + b*capacity*2 and its count to h_n_out[b].  No mask. */
+int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
+                    int pitch, size_t img_stride, int max_corners, double quality,
+                    double min_distance, int block_size, int aperture, int harris, double k,
+                    float* d_corners_xy, int capacity, int* h_n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

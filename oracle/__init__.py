@@ -1,0 +1,190 @@
+"""ctypes front for the CPU oracle (oracle/vofe_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this package; the
+product package (visual-odometry_amd) never does.  PARITY UNPINNED against cv2: see
+vofe_oracle.h.  Signatures mirror the cv2 calls made at reference continuous.py:145-151,
+continuous.py:380-385 and initialization.py:41-52.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TERM_CRITERIA_COUNT = 1
+TERM_CRITERIA_EPS = 2
+OPTFLOW_USE_INITIAL_FLOW = 4
+OPTFLOW_LK_GET_MIN_EIGENVALS = 8
+
+
+def build(force=False):
+    """Compile libvofe_oracle.so with the committed Makefile (g++ only)."""
+    so = os.path.join(_HERE, "libvofe_oracle.so")
+    src = os.path.join(_HERE, "vofe_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libvofe_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libvofe_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u8p, f32p, i32p, i16p = (C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int16))
+        L.vofe_cpu_pyr_down_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+        L.vofe_cpu_scharr_s16x2.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i16p, C.c_int]
+        L.vofe_cpu_pyramid_levels.argtypes = [C.c_int] * 5 + [i32p, i32p]
+        L.vofe_cpu_pyramid_level.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.vofe_cpu_lk_track.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p, f32p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_int, C.c_double, C.c_int]
+        L.vofe_cpu_track_fb.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p, f32p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_float, C.c_int]
+        L.vofe_cpu_corner_score.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
+        L.vofe_cpu_gftt.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p,
+                                    C.c_int, C.c_double, f32p, C.c_int, i32p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _img(a):
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise ValueError("image must be a 2-D uint8 array")
+    return np.ascontiguousarray(a)
+
+
+def pyr_down(img):
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    rc = lib().vofe_cpu_pyr_down_u8(_p(img, C.c_uint8), h, w, w, _p(out, C.c_uint8), out.shape[1])
+    assert rc == 0
+    return out
+
+
+def scharr(img):
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty((h, w, 2), np.int16)
+    rc = lib().vofe_cpu_scharr_s16x2(_p(img, C.c_uint8), h, w, w, _p(out, C.c_int16), 2 * w)
+    assert rc == 0
+    return out
+
+
+def pyramid_sizes(h, w, win, max_level):
+    lw = (C.c_int * (max_level + 1))()
+    lh = (C.c_int * (max_level + 1))()
+    n = lib().vofe_cpu_pyramid_levels(h, w, win[0], win[1], max_level, lw, lh)
+    return [(lh[i], lw[i]) for i in range(n)]
+
+
+def pyramid_level(img, level):
+    img = _img(img)
+    h, w = img.shape
+    for _ in range(level):
+        h, w = (h + 1) // 2, (w + 1) // 2
+    out = np.empty((h, w), np.uint8)
+    rc = lib().vofe_cpu_pyramid_level(_p(img, C.c_uint8), img.shape[0], img.shape[1], img.shape[1], level,
+                                      _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
+def _pts(p):
+    p = np.ascontiguousarray(np.asarray(p, np.float32).reshape(-1, 2))
+    return p
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
+                         criteria=(TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01), flags=0,
+                         minEigThreshold=1e-4, nthreads=1):
+    prevImg, nextImg = _img(prevImg), _img(nextImg)
+    if prevImg.shape != nextImg.shape:
+        raise ValueError("images must have the same size")
+    p = _pts(prevPts)
+    n = p.shape[0]
+    if n == 0:
+        return None, None, None
+    nxt = _pts(nextPts).copy() if (flags & OPTFLOW_USE_INITIAL_FLOW) else np.zeros_like(p)
+    st = np.empty(n, np.uint8)
+    err = np.empty(n, np.float32)
+    h, w = prevImg.shape
+    rc = lib().vofe_cpu_lk_track(_p(prevImg, C.c_uint8), _p(nextImg, C.c_uint8), h, w, w, _p(p, C.c_float),
+                                 _p(nxt, C.c_float), _p(st, C.c_uint8), _p(err, C.c_float), n,
+                                 int(winSize[0]), int(winSize[1]), int(maxLevel), int(criteria[0]),
+                                 int(criteria[1]), float(criteria[2]), int(flags), float(minEigThreshold),
+                                 int(nthreads))
+    if rc:
+        raise ValueError("vofe_cpu_lk_track: bad arguments (rc=%d)" % rc)
+    return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
+
+
+def track_keypoints(prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,
+                    criteria=(3, 30, 0.01), minEigThreshold=1e-3, fb_thresh=1.0, nthreads=1):
+    """Twin of ContinuousVO._track_keypoints (reference continuous.py:116-164)."""
+    prev_keypoints = np.asarray(prev_keypoints)
+    if prev_keypoints.size == 0:
+        return np.empty((2, 0)), np.empty((0,), np.uint8), np.empty((0,), np.float32)
+    img_prev, img_current = _img(img_prev), _img(img_current)
+    p = np.ascontiguousarray(prev_keypoints.T.reshape(-1, 2).astype(np.float32))
+    n = p.shape[0]
+    nxt = np.zeros_like(p)
+    st = np.empty(n, np.uint8)
+    err = np.empty(n, np.float32)
+    h, w = img_prev.shape
+    rc = lib().vofe_cpu_track_fb(_p(img_prev, C.c_uint8), _p(img_current, C.c_uint8), h, w, w, _p(p, C.c_float),
+                                 _p(nxt, C.c_float), _p(st, C.c_uint8), _p(err, C.c_float), n,
+                                 int(winSize[0]), int(winSize[1]), int(maxLevel), int(criteria[0]),
+                                 int(criteria[1]), float(criteria[2]), float(minEigThreshold),
+                                 float(fb_thresh), int(nthreads))
+    if rc:
+        raise ValueError("vofe_cpu_track_fb: bad arguments (rc=%d)" % rc)
+    return nxt.T, st, err
+
+
+def corner_score(img, harris=False, k=0.04, nthreads=1):
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.float32)
+    rc = lib().vofe_cpu_corner_score(_p(img, C.c_uint8), h, w, w, int(bool(harris)), float(k), _p(out, C.c_float),
+                                     int(nthreads))
+    assert rc == 0
+    return out
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
+                        useHarrisDetector=False, k=0.04, nthreads=1):
+    if blockSize != 3:
+        raise ValueError("oracle restates blockSize=3 only (the reference never passes another)")
+    img = _img(image)
+    h, w = img.shape
+    cap = maxCorners if maxCorners > 0 else h * w
+    out = np.empty((max(cap, 1), 2), np.float32)
+    n = C.c_int(0)
+    m = None
+    if mask is not None:
+        m = np.ascontiguousarray(np.asarray(mask, np.uint8))
+        if m.shape != img.shape:
+            raise ValueError("mask must match the image size")
+    rc = lib().vofe_cpu_gftt(_p(img, C.c_uint8), h, w, w, int(maxCorners), float(qualityLevel),
+                             float(minDistance), _p(m, C.c_uint8) if m is not None else None,
+                             int(bool(useHarrisDetector)), float(k), _p(out, C.c_float), cap, C.byref(n),
+                             int(nthreads))
+    if rc:
+        raise ValueError("vofe_cpu_gftt: bad arguments (rc=%d)" % rc)
+    if n.value == 0:
+        return None
+    return out[: n.value].reshape(-1, 1, 2).copy()

@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path (through the C ABI, libvofe.so) against the CPU oracle on the
+same seeded inputs.  Bars (BASELINE.json north_star): integer stages bit-exact; tracked positions
+within 0.05 px; status flags >= 99.5 % identical; corner sets identical.  Because both sides use
+the same canonical operation order the float stages are additionally expected to be bit-exact,
+which is asserted where it has been observed to hold."""
+import numpy as np
+import pytest
+
+import oracle
+from visual_odometry_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 0.05          # px, BASELINE.json north_star
+STATUS_MIN = 0.995      # fraction of identical status flags
+
+
+def _seq(h, w, seed, n=2):
+    return synthetic.sequence(h, w, seed=seed, n_frames=n)
+
+
+# ------------------------------------------------------------------ pyramid + Scharr (bit-exact)
+@pytest.mark.parametrize("h,w,win,levels", [(376, 1241, (21, 21), 3), (97, 131, (11, 11), 3),
+                                            (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
+                                            (33, 250, (5, 7), 2)])
+def test_pyramid_and_scharr_bit_exact(fe, h, w, win, levels):
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    imgs = _seq(h, w, seed=h + w, n=2)
+    pyr = Pyramid(fe, 2, h, w, win, levels, True)
+    pyr.build(torch.from_numpy(np.stack(imgs)).cuda(), 0)
+    sizes = oracle.pyramid_sizes(h, w, win, levels)
+    assert pyr.levels == len(sizes)
+    for slot in range(2):
+        for lvl in range(pyr.levels):
+            ref = oracle.pyramid_level(imgs[slot], lvl)
+            assert pyr.level_size(lvl) == sizes[lvl] == ref.shape
+            got, der = pyr.download(slot, lvl, deriv=True)
+            assert np.array_equal(got, ref), "level %d differs" % lvl
+            assert np.array_equal(der, oracle.scharr(ref)), "Scharr of level %d differs" % lvl
+            pad = pyr.download_padded(slot, lvl)
+            exp = np.pad(ref, ((win[1], win[1]), (win[0], win[0])), mode="reflect")
+            assert np.array_equal(pad, exp), "REFLECT_101 border of level %d differs" % lvl
+    pyr.free()
+
+
+def test_pyramid_rebuild_other_slot(fe):
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    a, b, c = _seq(120, 200, seed=9, n=3)
+    pyr = Pyramid(fe, 2, 120, 200, (21, 21), 3, True)
+    pyr.build(torch.from_numpy(np.stack([a, b])).cuda(), 0)
+    pyr.build(torch.from_numpy(c).cuda(), 1)
+    assert np.array_equal(pyr.download(0, 1), oracle.pyramid_level(a, 1))
+    assert np.array_equal(pyr.download(1, 2), oracle.pyramid_level(c, 2))
+    pyr.free()
+
+
+# ------------------------------------------------------------------ LK
+def _lk_compare(fe, a, b, pts, win, max_level, min_eig=1e-4, flags=0, init=None, criteria=(3, 30, 0.01)):
+    n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, win, max_level, criteria, flags, min_eig)
+    n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, win, max_level, criteria, flags, min_eig, nthreads=8)
+    s0, s1 = s0.ravel(), s1.ravel()
+    assert np.mean(s0 == s1) >= STATUS_MIN
+    ok = (s0 == 1) & (s1 == 1)
+    d = np.abs(n1.reshape(-1, 2) - n0.reshape(-1, 2))
+    assert d[ok].max(initial=0) <= POS_TOL
+    assert np.allclose(e1.ravel()[ok], e0.ravel()[ok], rtol=1e-5, atol=1e-6)
+    exact = np.array_equal(n1, n0) and np.array_equal(s0, s1) and np.array_equal(e1, e0)
+    return exact, n1, s1
+
+
+@pytest.mark.parametrize("h,w,seed,win,lvl,npts", [(376, 1241, 0, (21, 21), 3, 2000), (480, 640, 3, (11, 11), 3, 800),
+                                                   (600, 800, 1, (41, 41), 0, 400), (240, 320, 5, (31, 31), 4, 500),
+                                                   (200, 300, 6, (15, 9), 2, 300), (200, 300, 7, (7, 25), 2, 300)])
+def test_lk_matches_oracle(fe, h, w, seed, win, lvl, npts):
+    a, b = _seq(h, w, seed)
+    c = oracle.goodFeaturesToTrack(a, npts, 0.01, 7)
+    pts = synthetic.pad_points(c, npts, h, w, seed)
+    exact, nxt, st = _lk_compare(fe, a, b, pts, win, lvl)
+    assert exact, "HIP LK is expected to be bit-identical to the oracle"
+    assert st.sum() > 0.5 * npts
+
+
+def test_lk_flags_initial_flow_and_min_eig(fe):
+    a, b = _seq(240, 320, 12)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 300, 0.01, 7), 300, 240, 320, 12)
+    init = (pts + np.float32([1.0, 0.5])).astype(np.float32)
+    exact, _, _ = _lk_compare(fe, a, b, pts, (21, 21), 3, flags=4, init=init)
+    assert exact
+    exact, _, _ = _lk_compare(fe, a, b, pts, (21, 21), 3, flags=8, min_eig=1e-3)
+    assert exact
+    exact, _, _ = _lk_compare(fe, a, b, pts, (21, 21), 3, criteria=(1, 5, 0.01))
+    assert exact
+    exact, _, _ = _lk_compare(fe, a, b, pts, (21, 21), 3, criteria=(2, 30, 0.3))
+    assert exact
+
+
+def test_lk_out_of_bounds_flat_and_wild_points(fe):
+    a, b = _seq(120, 160, 21)
+    flat = np.full((120, 160), 77, np.uint8)
+    pts = np.float32([[-30, 5], [5, -30], [400, 50], [50, 400], [-11.5, -11.5], [159.9, 119.9], [0, 0],
+                      [80, 60], [np.nan, 3], [1e12, 1e12], [-1e20, 4], [np.inf, 0]])
+    for (x, y) in ((a, b), (flat, flat), (a, flat)):
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(x, y, pts, None, (21, 21), 2)
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(x, y, pts, None, (21, 21), 2)
+        assert np.array_equal(s0, s1)
+        assert np.array_equal(n0, n1, equal_nan=True)
+        assert np.array_equal(e0, e1, equal_nan=True)
+    n1, s1, _ = fe.calcOpticalFlowPyrLK(flat, flat, pts[6:8], None, (21, 21), 2)
+    assert s1.sum() == 0                     # flat patch fails the minEig test
+
+
+def test_lk_recovers_known_flow(fe):
+    h, w = 376, 1241
+    f = synthetic.sequence(h, w, seed=0, n_frames=2, noise_sigma=0.0)
+    c = fe.goodFeaturesToTrack(f[0], 500, 0.01, 10).reshape(-1, 2)
+    inner = (c[:, 0] > 40) & (c[:, 0] < w - 40) & (c[:, 1] > 40) & (c[:, 1] < h - 40)
+    nxt, st, _ = fe.calcOpticalFlowPyrLK(f[0], f[1], c[inner], None, (21, 21), 3)
+    truth = synthetic.true_flow(c[inner], h, w, 0, 1)
+    ok = st.ravel() == 1
+    assert ok.mean() > 0.95
+    assert np.median(np.abs(nxt.reshape(-1, 2)[ok] - truth[ok])) < 0.05
+
+
+def test_track_keypoints_twin(fe):
+    h, w = 376, 1241
+    a, b = _seq(h, w, 0)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 2000, 0.01, 7), 2000, h, w, 0)
+    t1, s1, e1 = fe.track_keypoints(pts.T, a, b, (21, 21), 3, (3, 30, 0.01), 1e-3)
+    t0, s0, e0 = oracle.track_keypoints(pts.T, a, b, (21, 21), 3, (3, 30, 0.01), 1e-3, nthreads=8)
+    assert t1.shape == (2, 2000) and s1.shape == (2000,) and e1.shape == (2000,)
+    assert t1.dtype == np.float32 and s1.dtype == np.uint8 and e1.dtype == np.float32
+    assert np.mean(s0 == s1) >= STATUS_MIN
+    ok = (s0 == 1) & (s1 == 1)
+    assert np.abs(t1 - t0)[:, ok].max() <= POS_TOL
+    assert np.array_equal(t1, t0) and np.array_equal(s1, s0) and np.array_equal(e1, e0)
+    # empty input (reference continuous.py:131-132)
+    t, s, e = fe.track_keypoints(np.empty((2, 0)), a, b)
+    assert t.shape == (2, 0) and s.shape == (0,) and s.dtype == np.uint8 and e.dtype == np.float32
+
+
+def test_lk_bad_arguments_raise(fe):
+    from visual_odometry_amd import error
+    a, b = _seq(64, 64, 1)
+    pts = np.float32([[10, 10]])
+    with pytest.raises(error):
+        fe.calcOpticalFlowPyrLK(a, b, pts, None, (2, 2), 3)
+    with pytest.raises(error):
+        fe.calcOpticalFlowPyrLK(a, b, pts, None, (21, 21), -1)
+    with pytest.raises(error):
+        fe.calcOpticalFlowPyrLK(a, b[:32], pts, None, (21, 21), 1)
+    with pytest.raises(error):
+        fe.calcOpticalFlowPyrLK(a, b, pts.astype(np.float64), None, (21, 21), 1)
+    assert fe.calcOpticalFlowPyrLK(a, b, np.zeros((0, 1, 2), np.float32)) == (None, None, None)
+
+
+# ------------------------------------------------------------------ corners
+@pytest.mark.parametrize("h,w,seed", [(376, 1241, 0), (600, 800, 1), (97, 131, 4), (3, 3, 2), (1, 50, 2), (40, 2, 2)])
+@pytest.mark.parametrize("harris", [False, True])
+def test_corner_score_bit_exact(fe, h, w, seed, harris):
+    a = _seq(h, w, seed, 1)[0]
+    got = fe.corner_score(a, harris, 0.04)
+    ref = oracle.corner_score(a, harris, 0.04, nthreads=8)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("h,w,seed,maxc,q,md", [(376, 1241, 0, 1000, 0.01, 10), (376, 1241, 0, 2000, 0.01, 7),
+                                                (600, 800, 1, 3000, 0.01, 10), (600, 800, 1, 400, 0.01, 10),
+                                                (480, 640, 3, 1000, 0.01, 10), (200, 300, 8, 0, 0.05, 5.5),
+                                                (200, 300, 8, 50, 0.3, 0), (200, 300, 8, 100, 0.01, 0.5),
+                                                (200, 300, 8, 0, 0.001, 1), (200, 300, 8, 10000, 0.001, 2.5)])
+def test_gftt_identical_corner_sets(fe, h, w, seed, maxc, q, md):
+    a = _seq(h, w, seed, 1)[0]
+    got = fe.goodFeaturesToTrack(a, maxc, q, md)
+    ref = oracle.goodFeaturesToTrack(a, maxc, q, md, nthreads=8)
+    assert (got is None) == (ref is None)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.array_equal(got, ref)            # identical set AND identical order
+
+
+def test_gftt_harris_mask_and_degenerate(fe):
+    a = _seq(200, 300, 8, 1)[0]
+    got = fe.goodFeaturesToTrack(a, 200, 0.01, 8, useHarrisDetector=True, k=0.04)
+    assert np.array_equal(got, oracle.goodFeaturesToTrack(a, 200, 0.01, 8, useHarrisDetector=True, k=0.04))
+    mask = np.zeros_like(a)
+    mask[50:150, 100:250] = 255
+    got = fe.goodFeaturesToTrack(a, 200, 0.01, 8, mask=mask)
+    ref = oracle.goodFeaturesToTrack(a, 200, 0.01, 8, mask=mask)
+    assert np.array_equal(got, ref)
+    assert (got[:, 0, 0] >= 100).all() and (got[:, 0, 1] < 150).all()
+    assert fe.goodFeaturesToTrack(a, 200, 0.01, 8, mask=np.zeros_like(a)) is None
+    assert fe.goodFeaturesToTrack(np.full((50, 60), 9, np.uint8), 100, 0.01, 5) is None      # constant image
+    ramp = np.tile(np.arange(0, 240, 2, dtype=np.uint8), (60, 1))
+    assert (fe.goodFeaturesToTrack(ramp, 10, 0.01, 5) is None) == (oracle.goodFeaturesToTrack(ramp, 10, 0.01, 5) is None)
+
+
+def test_gftt_plateaus_and_ties(fe):
+    """Isolated squares give exactly tied scores: order must be 'larger linear index first'."""
+    a = np.zeros((120, 160), np.uint8)
+    for (y, x) in ((20, 20), (20, 100), (80, 30), (70, 120)):
+        a[y:y + 12, x:x + 12] = 200
+    for md in (0, 1, 3, 20):
+        got = fe.goodFeaturesToTrack(a, 0, 0.01, md)
+        ref = oracle.goodFeaturesToTrack(a, 0, 0.01, md)
+        assert np.array_equal(got, ref)
+    chk = (np.indices((96, 128)).sum(0) // 8 % 2 * 255).astype(np.uint8)     # periodic: massive ties
+    for md in (0, 4, 10):
+        assert np.array_equal(fe.goodFeaturesToTrack(chk, 0, 0.01, md), oracle.goodFeaturesToTrack(chk, 0, 0.01, md))
+
+
+def test_gftt_large_sort(fe):
+    """More accepted corners than one LDS sort chunk (8192): exercises the global bitonic steps."""
+    a = _seq(700, 900, 31, 1)[0]
+    got = fe.goodFeaturesToTrack(a, 0, 0.0005, 1)
+    ref = oracle.goodFeaturesToTrack(a, 0, 0.0005, 1, nthreads=8)
+    assert ref.shape[0] > 8192
+    assert np.array_equal(got, ref)
+    got = fe.goodFeaturesToTrack(a, 20000, 0.0005, 0)
+    ref = oracle.goodFeaturesToTrack(a, 20000, 0.0005, 0, nthreads=8)
+    assert ref.shape[0] == 20000 and np.array_equal(got, ref)
+
+
+def test_gftt_batch(fe):
+    import torch
+    imgs = np.stack([_seq(200, 300, 40 + i, 1)[0] for i in range(5)])
+    out, cnt = fe.goodFeaturesToTrack_batch(torch.from_numpy(imgs).cuda(), 300, 0.01, 9)
+    out = out.cpu().numpy()
+    for i in range(5):
+        ref = oracle.goodFeaturesToTrack(imgs[i], 300, 0.01, 9)
+        assert cnt[i] == ref.shape[0]
+        assert np.array_equal(out[i, :cnt[i]], ref.reshape(-1, 2))
+
+
+def test_gftt_bad_arguments_raise(fe):
+    from visual_odometry_amd import error
+    a = _seq(64, 64, 1, 1)[0]
+    for args in ((10, 0.0, 5), (10, 0.01, -1), (-1, 0.01, 5)):
+        with pytest.raises(error):
+            fe.goodFeaturesToTrack(a, *args)
+    with pytest.raises(error):
+        fe.goodFeaturesToTrack(a.astype(np.float32), 10, 0.01, 5)

@@ -1,0 +1,66 @@
+"""ctypes binding of libvofe.so (C ABI in include/vofe.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvofe.so")
+
+# every symbol include/vofe.h declares (tests check the built library exports all of them)
+SYMBOLS = (
+    "vofe_last_error", "vofe_version", "vofe_create", "vofe_destroy", "vofe_synchronize",
+    "vofe_pyramid_create", "vofe_pyramid_free", "vofe_pyramid_build", "vofe_pyramid_levels",
+    "vofe_pyramid_level_size", "vofe_pyramid_download", "vofe_pyramid_download_padded",
+    "vofe_lk_track", "vofe_track_fb", "vofe_corner_score", "vofe_gftt", "vofe_gftt_batch",
+)
+
+_lib = None
+
+
+class error(Exception):
+    """Raised where cv2 would raise cv2.error (bad arguments) and on HIP failures."""
+
+    def __init__(self, code, msg):
+        super().__init__("vofe error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvofe.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, d, f, sz = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t
+    ip = C.POINTER(C.c_int)
+    L.vofe_last_error.restype = C.c_char_p
+    L.vofe_last_error.argtypes = []
+    L.vofe_version.argtypes = []
+    L.vofe_create.argtypes = [i, vp, C.POINTER(vp)]
+    L.vofe_destroy.argtypes = [vp]
+    L.vofe_synchronize.argtypes = [vp]
+    L.vofe_pyramid_create.argtypes = [vp, i, i, i, i, i, i, i, C.POINTER(vp)]
+    L.vofe_pyramid_free.argtypes = [vp, vp]
+    L.vofe_pyramid_build.argtypes = [vp, vp, i, i, vp, i, sz]
+    L.vofe_pyramid_levels.argtypes = [vp]
+    L.vofe_pyramid_level_size.argtypes = [vp, i, ip, ip]
+    L.vofe_pyramid_download.argtypes = [vp, vp, i, i, vp, vp]
+    L.vofe_pyramid_download_padded.argtypes = [vp, vp, i, i, i, i, vp]
+    L.vofe_lk_track.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, i, d]
+    L.vofe_track_fb.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, d, f]
+    L.vofe_corner_score.argtypes = [vp, vp, i, i, i, i, sz, i, i, i, d, vp]
+    L.vofe_gftt.argtypes = [vp, vp, i, i, i, i, d, d, vp, i, i, i, d, vp, i, ip]
+    L.vofe_gftt_batch.argtypes = [vp, vp, i, i, i, i, sz, i, d, d, i, i, i, d, vp, i, ip]
+    for name in SYMBOLS:
+        if name != "vofe_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise error(rc, load().vofe_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,303 @@
+// C ABI of libvofe.so (declared in include/vofe.h): argument checks that mirror the cv2 asserts,
+// context / pyramid object management, and dispatch to the kernel launchers.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vofe_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void vofe_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int vofe_hip_fail(hipError_t e, const char* what) {
+    vofe_set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return VOFE_E_HIP;
+}
+
+static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+extern "C" {
+
+const char* vofe_last_error(void) { return g_err; }
+int vofe_version(void) { return 100; }
+
+int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
+    if (!out) { vofe_set_error("vofe_create: out is NULL"); return VOFE_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        vofe_set_error("vofe_create: no HIP device available (%s); this library has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return VOFE_E_HIP;
+    }
+    if (device < 0 || device >= ndev) { vofe_set_error("vofe_create: device %d out of range [0,%d)", device, ndev); return VOFE_E_ARG; }
+    VOFE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VOFE_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        vofe_set_error("vofe_create: device %d is %s; libvofe is built for gfx950 only", device, prop.gcnArchName);
+        return VOFE_E_UNSUPPORTED;
+    }
+    vofe_ctx* c = new (std::nothrow) vofe_ctx();
+    if (!c) return VOFE_E_NOMEM;
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->ws = nullptr; c->ws_bytes = 0;
+    c->h_pinned = nullptr; c->h_pinned_ints = 0;
+    *out = c;
+    return VOFE_OK;
+}
+
+int vofe_destroy(vofe_ctx* ctx) {
+    if (!ctx) return VOFE_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    delete ctx;
+    return VOFE_OK;
+}
+
+int vofe_synchronize(vofe_ctx* ctx) {
+    if (!ctx) { vofe_set_error("vofe_synchronize: ctx is NULL"); return VOFE_E_ARG; }
+    VOFE_HIP(hipStreamSynchronize(ctx->stream));
+    return VOFE_OK;
+}
+
+// ------------------------------------------------------------------------------- pyramids
+int vofe_pyramid_create(vofe_ctx* ctx, int slots, int height, int width, int win_w, int win_h,
+                        int max_level, int with_deriv, vofe_pyr** out) {
+    if (!ctx || !out) { vofe_set_error("vofe_pyramid_create: NULL argument"); return VOFE_E_ARG; }
+    *out = nullptr;
+    if (slots <= 0 || height <= 0 || width <= 0) { vofe_set_error("vofe_pyramid_create: empty image or no slots"); return VOFE_E_ARG; }
+    if (max_level < 0 || win_w <= 2 || win_h <= 2) {      // cv2 assert: maxLevel >= 0 && winSize > 2
+        vofe_set_error("vofe_pyramid_create: need maxLevel >= 0 and winSize > 2 (got %d, %dx%d)", max_level, win_w, win_h);
+        return VOFE_E_ARG;
+    }
+    if (height + 2 * win_h > 65535) { vofe_set_error("vofe_pyramid_create: image too tall (%d rows)", height); return VOFE_E_UNSUPPORTED; }
+    vofe_pyr* p = new (std::nothrow) vofe_pyr();
+    if (!p) return VOFE_E_NOMEM;
+    memset(p, 0, sizeof(*p));
+    p->slots = slots; p->height = height; p->width = width;
+    p->win_w = win_w; p->win_h = win_h; p->with_deriv = with_deriv ? 1 : 0;
+    p->pad_x = (int)align_up(win_w + 20, 16);
+    p->pad_y = win_h;
+    // stop when the next level would not exceed the window
+    int w = width, h = height, n = 0;
+    long long total = 0;
+    long long base[VOFE_MAX_LEVELS];
+    for (int level = 0; level <= max_level && n < VOFE_MAX_LEVELS; ++level) {
+        VofeLevel& L = p->lv[n];
+        L.w = w; L.h = h;
+        L.pitch = (int)align_up(w + 2 * p->pad_x, 64);
+        L.rows = h + 2 * p->pad_y;
+        L.slot_stride = align_up((long long)L.pitch * L.rows, 64);
+        base[n] = total;
+        total += L.slot_stride * slots;
+        ++n;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win_w || h <= win_h) break;
+    }
+    p->levels = n;
+    VOFE_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc((void**)&p->d_I, (size_t)total + 256);
+    if (e != hipSuccess) { delete p; return vofe_hip_fail(e, "hipMalloc(pyramid images)"); }
+    hipMemsetAsync(p->d_I, 0, (size_t)total + 256, ctx->stream);
+    if (p->with_deriv) {
+        e = hipMalloc((void**)&p->d_D, ((size_t)total + 64) * 4);
+        if (e != hipSuccess) { hipFree(p->d_I); delete p; return vofe_hip_fail(e, "hipMalloc(pyramid derivatives)"); }
+        hipMemsetAsync(p->d_D, 0, ((size_t)total + 64) * 4, ctx->stream);
+    }
+    for (int l = 0; l < n; ++l) {
+        VofeLevel& L = p->lv[l];
+        const long long o = base[l] + (long long)p->pad_y * L.pitch + p->pad_x;
+        L.I = p->d_I + o;
+        L.D = p->d_D ? p->d_D + o : nullptr;
+    }
+    e = hipMalloc((void**)&p->d_lv, sizeof(VofeLevel) * VOFE_MAX_LEVELS);
+    if (e != hipSuccess) { hipFree(p->d_I); if (p->d_D) hipFree(p->d_D); delete p; return vofe_hip_fail(e, "hipMalloc(level table)"); }
+    e = hipMemcpyAsync(p->d_lv, p->lv, sizeof(VofeLevel) * VOFE_MAX_LEVELS, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { vofe_pyramid_free(ctx, p); return vofe_hip_fail(e, "pyramid table upload"); }
+    *out = p;
+    return VOFE_OK;
+}
+
+int vofe_pyramid_free(vofe_ctx* ctx, vofe_pyr* pyr) {
+    if (!pyr) return VOFE_OK;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    if (pyr->d_I) hipFree(pyr->d_I);
+    if (pyr->d_D) hipFree(pyr->d_D);
+    if (pyr->d_lv) hipFree(pyr->d_lv);
+    delete pyr;
+    return VOFE_OK;
+}
+
+int vofe_pyramid_build(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, const uint8_t* d_img,
+                       int pitch, size_t img_stride) {
+    if (!ctx || !pyr || !d_img) { vofe_set_error("vofe_pyramid_build: NULL argument"); return VOFE_E_ARG; }
+    if (slot0 < 0 || count <= 0 || slot0 + count > pyr->slots) {
+        vofe_set_error("vofe_pyramid_build: slots [%d,%d) outside [0,%d)", slot0, slot0 + count, pyr->slots);
+        return VOFE_E_ARG;
+    }
+    if (pitch < pyr->width) { vofe_set_error("vofe_pyramid_build: pitch %d < width %d", pitch, pyr->width); return VOFE_E_ARG; }
+    if (count > 65535) { vofe_set_error("vofe_pyramid_build: count %d > 65535", count); return VOFE_E_UNSUPPORTED; }
+    return vofe_launch_pyramid(ctx, pyr, slot0, count, d_img, pitch, img_stride);
+}
+
+int vofe_pyramid_levels(const vofe_pyr* pyr) { return pyr ? pyr->levels : VOFE_E_ARG; }
+
+int vofe_pyramid_level_size(const vofe_pyr* pyr, int level, int* width, int* height) {
+    if (!pyr || level < 0 || level >= pyr->levels) { vofe_set_error("vofe_pyramid_level_size: bad level"); return VOFE_E_ARG; }
+    if (width) *width = pyr->lv[level].w;
+    if (height) *height = pyr->lv[level].h;
+    return VOFE_OK;
+}
+
+int vofe_pyramid_download_padded(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int level,
+                                 int pad_x, int pad_y, uint8_t* h_image) {
+    if (!ctx || !pyr || !h_image || slot < 0 || slot >= pyr->slots || level < 0 || level >= pyr->levels ||
+        pad_x < 0 || pad_y < 0 || pad_x > pyr->win_w || pad_y > pyr->win_h) {
+        vofe_set_error("vofe_pyramid_download_padded: bad argument");
+        return VOFE_E_ARG;
+    }
+    const VofeLevel& L = pyr->lv[level];
+    VOFE_HIP(hipStreamSynchronize(ctx->stream));
+    const uint8_t* src = L.I + (long long)slot * L.slot_stride - (long long)pad_y * L.pitch - pad_x;
+    const size_t wbytes = (size_t)L.w + 2 * pad_x;
+    VOFE_HIP(hipMemcpy2D(h_image, wbytes, src, (size_t)L.pitch, wbytes, (size_t)L.h + 2 * pad_y, hipMemcpyDeviceToHost));
+    return VOFE_OK;
+}
+
+int vofe_pyramid_download(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int level,
+                          uint8_t* h_image, int16_t* h_deriv) {
+    if (!ctx || !pyr || slot < 0 || slot >= pyr->slots || level < 0 || level >= pyr->levels) {
+        vofe_set_error("vofe_pyramid_download: bad argument");
+        return VOFE_E_ARG;
+    }
+    const VofeLevel& L = pyr->lv[level];
+    VOFE_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_image)
+        VOFE_HIP(hipMemcpy2D(h_image, (size_t)L.w, L.I + (long long)slot * L.slot_stride, (size_t)L.pitch, (size_t)L.w,
+                             (size_t)L.h, hipMemcpyDeviceToHost));
+    if (h_deriv) {
+        if (!L.D) { vofe_set_error("vofe_pyramid_download: pyramid has no derivative planes"); return VOFE_E_ARG; }
+        VOFE_HIP(hipMemcpy2D(h_deriv, (size_t)L.w * 4, L.D + (long long)slot * L.slot_stride, (size_t)L.pitch * 4,
+                             (size_t)L.w * 4, (size_t)L.h, hipMemcpyDeviceToHost));
+    }
+    return VOFE_OK;
+}
+
+// ------------------------------------------------------------------------------- LK
+static int lk_common(const char* who, vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                     int next_slot, const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                     int n, int need_next_deriv) {
+    if (!ctx || !prev || !next) { vofe_set_error("%s: NULL ctx or pyramid", who); return VOFE_E_ARG; }
+    if (n < 0) { vofe_set_error("%s: n < 0", who); return VOFE_E_ARG; }
+    if (n > 0 && (!d_prev_pts || !d_next_pts || !d_status || !d_err)) { vofe_set_error("%s: NULL point buffer", who); return VOFE_E_ARG; }
+    if (prev->height != next->height || prev->width != next->width || prev->win_w != next->win_w ||
+        prev->win_h != next->win_h || prev->levels != next->levels) {
+        vofe_set_error("%s: prev and next pyramids differ in geometry (cv2 asserts equal size/type)", who);
+        return VOFE_E_ARG;
+    }
+    if (!prev->with_deriv || (need_next_deriv && !next->with_deriv)) {
+        vofe_set_error("%s: pyramid built without derivative planes", who);
+        return VOFE_E_ARG;
+    }
+    if (prev_slot < 0 || prev_slot >= prev->slots || next_slot < 0 || next_slot >= next->slots) {
+        vofe_set_error("%s: slot out of range", who);
+        return VOFE_E_ARG;
+    }
+    return VOFE_OK;
+}
+static void lk_criteria(int type, int& max_count, double& eps) {
+    max_count = (type & 1) ? (max_count < 0 ? 0 : (max_count > 100 ? 100 : max_count)) : 30;
+    eps = (type & 2) ? (eps < 0 ? 0 : (eps > 10 ? 10 : eps)) : 0.01;
+    eps *= eps;
+}
+
+int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
+                  int flags, double min_eig_thr) {
+    int rc = lk_common("vofe_lk_track", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 0);
+    if (rc || n == 0) return rc;
+    lk_criteria(crit_type, max_count, eps);
+    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
+                          max_count, eps, flags, (float)min_eig_thr, 0, 0.f);
+}
+
+int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
+                  double min_eig_thr, float fb_thresh) {
+    int rc = lk_common("vofe_track_fb", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 1);
+    if (rc || n == 0) return rc;
+    lk_criteria(crit_type, max_count, eps);
+    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
+                          max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
+}
+
+// ------------------------------------------------------------------------------- corners
+static int corner_args(const char* who, vofe_ctx* ctx, const uint8_t* d_img, int h, int w, int pitch, int block_size, int aperture) {
+    if (!ctx || !d_img) { vofe_set_error("%s: NULL argument", who); return VOFE_E_ARG; }
+    if (h <= 0 || w <= 0 || pitch < w) { vofe_set_error("%s: bad image geometry %dx%d pitch %d", who, w, h, pitch); return VOFE_E_ARG; }
+    if (block_size != 3 || aperture != 3) {
+        vofe_set_error("%s: only blockSize=3, gradientSize=3 are implemented (the reference passes neither: continuous.py:380-385)", who);
+        return VOFE_E_UNSUPPORTED;
+    }
+    return VOFE_OK;
+}
+
+int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
+                      int pitch, size_t img_stride, int block_size, int aperture, int harris,
+                      double k, float* d_score) {
+    int rc = corner_args("vofe_corner_score", ctx, d_img, height, width, pitch, block_size, aperture);
+    if (rc) return rc;
+    if (!d_score || batch <= 0) { vofe_set_error("vofe_corner_score: NULL score buffer or batch <= 0"); return VOFE_E_ARG; }
+    return vofe_launch_corner_score(ctx, d_img, batch, height, width, pitch, img_stride, harris, (float)k, d_score, nullptr, nullptr);
+}
+
+int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
+              int max_corners, double quality, double min_distance, const uint8_t* d_mask,
+              int block_size, int aperture, int harris, double k, float* d_corners_xy,
+              int capacity, int* h_n_out) {
+    if (!h_n_out) { vofe_set_error("vofe_gftt: h_n_out is NULL"); return VOFE_E_ARG; }
+    *h_n_out = 0;
+    if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0) {       // SURVEY A.2 asserts
+        vofe_set_error("vofe_gftt: need qualityLevel > 0, minDistance >= 0, maxCorners >= 0");
+        return VOFE_E_ARG;
+    }
+    int rc = corner_args("vofe_gftt", ctx, d_img, height, width, pitch, block_size, aperture);
+    if (rc) return rc;
+    if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt: bad output buffer"); return VOFE_E_ARG; }
+    return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
+                          d_corners_xy, capacity, h_n_out);
+}
+
+int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
+                    int pitch, size_t img_stride, int max_corners, double quality,
+                    double min_distance, int block_size, int aperture, int harris, double k,
+                    float* d_corners_xy, int capacity, int* h_n_out) {
+    if (!h_n_out || batch <= 0) { vofe_set_error("vofe_gftt_batch: h_n_out is NULL or batch <= 0"); return VOFE_E_ARG; }
+    for (int b = 0; b < batch; ++b) h_n_out[b] = 0;
+    if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0) {
+        vofe_set_error("vofe_gftt_batch: need qualityLevel > 0, minDistance >= 0, maxCorners >= 0");
+        return VOFE_E_ARG;
+    }
+    int rc = corner_args("vofe_gftt_batch", ctx, d_img, height, width, pitch, block_size, aperture);
+    if (rc) return rc;
+    if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt_batch: bad output buffer"); return VOFE_E_ARG; }
+    return vofe_gftt_impl(ctx, d_img, batch, height, width, pitch, img_stride, max_corners, quality, min_distance, nullptr,
+                          harris, k, d_corners_xy, capacity, h_n_out);
+}
+
+}  // extern "C"

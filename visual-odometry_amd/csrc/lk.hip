@@ -1,0 +1,333 @@
+// Pyramidal Lucas-Kanade tracker for gfx950: one wavefront (64 lanes) per keypoint, all pyramid
+// levels, the optional backward pass and the forward-backward check inside one launch.
+//
+// Replaces cv::LKTrackerInvoker (cv2.calcOpticalFlowPyrLK at reference continuous.py:145-146,
+// 150-151, initialization.py:51-52) and the glue of ContinuousVO._track_keypoints
+// (continuous.py:131-164).  Arithmetic per SURVEY.md A.5 with the canonical choices stated in
+// oracle/vofe_oracle.cpp: integer window sums are exact (order-free), float steps are evaluated
+// in the written order with -ffp-contract=off, so results are bit-identical to the oracle.
+//
+// Mapping: lane -> (column x of the window, row group g); a lane owns up to R vertically adjacent
+// window pixels, so the bilinear taps of row r+1 are reused as the top taps of the next pixel.
+// The template window (I, Ix, Iy at the fixed prev position) lives in registers; the search image
+// J is staged once per level into LDS as (J[x] | J[x+1] << 16) pairs around the start position
+// (margin LK_MARGIN px) and re-staged only if the Gauss-Newton walk leaves it.  Window sums are
+// reduced with DPP row rotations + 4 readlanes.  Not HBM- or MFMA-bound: gather + VALU + LDS.
+#include "vofe_internal.h"
+
+namespace {
+
+constexpr int LK_MARGIN = 4;
+constexpr int W_BITS = 14;
+
+struct LKArgs {
+    const VofeLevel* lv_a;     // pyramid in the "prev" role of the forward pass
+    const VofeLevel* lv_b;     // pyramid in the "next" role of the forward pass
+    int n_levels;
+    int slot_a, slot_b;
+    const float2* prev_pts;
+    const int* img_idx;
+    float2* next_pts;
+    uint8_t* status;
+    float* err;
+    int n;
+    int win_w, win_h;
+    int groups, rows_per_group;
+    int max_count, flags, fb;
+    float min_eig_thr, fb_thresh;
+    double eps2;
+    int rw, rh;                // LDS region size in pixels
+};
+
+__device__ __forceinline__ int floor_i(float v) {
+    if (!(v > -1073741824.f && v < 1073741824.f)) return INT_MIN;
+    int i = (int)v;
+    return i - ((float)i > v);
+}
+__device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
+
+// exact wave-wide sum of one int32 per lane, as int64 (all 64 lanes must be active)
+__device__ __forceinline__ int row_sum16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ int wave_sum_small(int v) {                 // |sum| must fit int32
+    v = row_sum16(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ long long wave_sum_i64(int v) {
+    const int lo = wave_sum_small(v & 0xffff);
+    const int hi = wave_sum_small(v >> 16);
+    return (long long)hi * 65536 + (long long)lo;
+}
+
+struct Wts { unsigned w0, w1; int w00, w01, w10, w11; };
+__device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int iy) {
+    const float a = fx - (float)ix, b = fy - (float)iy;
+    Wts q;
+    q.w00 = round_i((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
+    q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
+    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
+    q.w0 = (unsigned)q.w00 | ((unsigned)q.w01 << 16);
+    q.w1 = (unsigned)q.w10 | ((unsigned)q.w11 << 16);
+    return q;
+}
+
+// stage the (rw x rh) region of J whose top-left pixel is (rx0, ry0) as (J[x] | J[x+1]<<16)
+__device__ __forceinline__ void stage_region(unsigned* lds, const uint8_t* __restrict__ J0, const VofeLevel& B,
+                                             int win_w, int win_h, int rx0, int ry0, int rw, int rh, int lane) {
+    const int xmin = -win_w, xmax = B.w + win_w - 1, ymin = -win_h, ymax = B.h + win_h - 1;
+    int cx = lane % rw, cy = lane / rw;
+    const int sx = 64 % rw, sy = 64 / rw;
+    const int total = rw * rh;
+    for (int e = lane; e < total; e += 64) {
+        const int gy = min(max(ry0 + cy, ymin), ymax);
+        const int gxa = min(max(rx0 + cx, xmin), xmax);
+        const int gxb = min(max(rx0 + cx + 1, xmin), xmax);
+        const uint8_t* r = J0 + (long long)gy * B.pitch;
+        lds[e] = (unsigned)r[gxa] | ((unsigned)r[gxb] << 16);
+        cx += sx; cy += sy;
+        if (cx >= rw) { cx -= rw; ++cy; }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
+                                       int slotA, int slotB, float px, float py, float& outx, float& outy,
+                                       int& status, float& err, int flags, unsigned* lds, int lane, int x, int y0,
+                                       int ny) {
+    const int w = a.win_w, h = a.win_h;
+    const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
+    const int top = a.n_levels - 1;
+    const int rw = a.rw, rh = a.rh;
+    for (int level = top; level >= 0; --level) {
+        const VofeLevel A = LA[level];
+        const VofeLevel B = LB[level];
+        const float sc = 1.0f / (float)(1 << level);
+        float ppx = px * sc, ppy = py * sc;
+        float npx, npy;
+        if (level == top) {
+            if (flags & 4) { npx = outx * sc; npy = outy * sc; }
+            else { npx = ppx; npy = ppy; }
+        } else { npx = outx * 2.f; npy = outy * 2.f; }
+        outx = npx; outy = npy;
+        ppx -= hx; ppy -= hy;
+        const int ipx = floor_i(ppx), ipy = floor_i(ppy);
+        if (ipx < -w || ipx >= A.w || ipy < -h || ipy >= A.h) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        // ---- template window: I, Ix, Iy at the fixed prev position -> registers
+        int Ival[R], Dval[R];
+        long long sA11, sA12, sA22;
+        {
+            const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
+            const long long base = (long long)slotA * A.slot_stride + (long long)(ipy + y0) * A.pitch + ipx + x;
+            const uint8_t* Ib = A.I + base;
+            const int* Db = A.D + base;
+            unsigned pI[R + 1];
+            int dA[R + 1], dB[R + 1];
+#pragma unroll
+            for (int r = 0; r <= R; ++r) {
+                const long long off = (long long)min(r, ny) * A.pitch;
+                pI[r] = (unsigned)Ib[off] | ((unsigned)Ib[off + 1] << 16);
+                dA[r] = Db[off];
+                dB[r] = Db[off + 1];
+            }
+            int a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int iv = (int)(udot2(pI[k], q.w0, udot2(pI[k + 1], q.w1, 256u)) >> 9);
+                int ix = ((int)(short)dA[k] * q.w00 + (int)(short)dB[k] * q.w01 + (int)(short)dA[k + 1] * q.w10 +
+                          (int)(short)dB[k + 1] * q.w11 + 8192) >> 14;
+                int iy = ((dA[k] >> 16) * q.w00 + (dB[k] >> 16) * q.w01 + (dA[k + 1] >> 16) * q.w10 +
+                          (dB[k + 1] >> 16) * q.w11 + 8192) >> 14;
+                if (k >= ny) { ix = 0; iy = 0; }
+                Ival[k] = iv;
+                Dval[k] = (ix & 0xffff) | (iy << 16);
+                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+            }
+            sA11 = wave_sum_i64(a11); sA12 = wave_sum_i64(a12); sA22 = wave_sum_i64(a22);
+        }
+        const float FLT_SCALE = 1.f / (float)(1 << 20);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float Dd = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
+        if (flags & 8) err = minEig;
+        if (minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        Dd = 1.f / Dd;
+        npx -= hx; npy -= hy;
+        float pdx = 0.f, pdy = 0.f;
+        const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
+        bool staged = false;
+        int rx0 = 0, ry0 = 0;
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = floor_i(npx), iny = floor_i(npy);
+            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                __syncthreads();
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                stage_region(lds, J0, B, w, h, rx0, ry0, rw, rh, lane);
+                staged = true;
+                __syncthreads();
+            }
+            const Wts q = bilinear_weights(npx, npy, inx, iny);
+            const unsigned* lp = lds + (iny - ry0 + y0) * rw + (inx - rx0) + x;
+            unsigned P[R + 1];
+#pragma unroll
+            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rw];
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int jv = (int)(udot2(P[k], q.w0, udot2(P[k + 1], q.w1, 256u)) >> 9);
+                const int diff = jv - Ival[k];
+                b1 += diff * (int)(short)Dval[k];
+                b2 += diff * (Dval[k] >> 16);
+            }
+            const long long sb1 = wave_sum_i64(b1), sb2 = wave_sum_i64(b2);
+            const float fb1 = (float)sb1 * FLT_SCALE, fb2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * Dd;
+            const float dy = (A12 * fb1 - A11 * fb2) * Dd;
+            npx += dx; npy += dy;
+            outx = npx + hx; outy = npy + hy;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0 && !(flags & 8)) {
+            const float ex = outx - hx, ey = outy - hy;
+            const int inx = floor_i(ex), iny = floor_i(ey);
+            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) { status = 0; continue; }
+            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                __syncthreads();
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                stage_region(lds, J0, B, w, h, rx0, ry0, rw, rh, lane);
+                staged = true;
+                __syncthreads();
+            }
+            const Wts q = bilinear_weights(ex, ey, inx, iny);
+            const unsigned* lp = lds + (iny - ry0 + y0) * rw + (inx - rx0) + x;
+            unsigned P[R + 1];
+#pragma unroll
+            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rw];
+            int se = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int jv = (int)(udot2(P[k], q.w0, udot2(P[k + 1], q.w1, 256u)) >> 9);
+                const int diff = jv - Ival[k];
+                se += (k < ny) ? abs(diff) : 0;
+            }
+            const long long ses = wave_sum_i64(se);
+            err = (float)ses / (float)(32 * w * h);
+        }
+        __syncthreads();     // all LDS reads of this level done before the next level restages
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
+    extern __shared__ unsigned lds[];
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int g = lane / a.win_w;
+    const int x = lane - g * a.win_w;
+    const bool active = g < a.groups;
+    const int y0 = min(g * a.rows_per_group, a.win_h);
+    const int ny = active ? min(a.rows_per_group, a.win_h - y0) : 0;
+
+    const float2 p = a.prev_pts[i];
+    const int idx = a.img_idx ? a.img_idx[i] : 0;
+    float fx = 0.f, fy = 0.f;
+    if (a.flags & 4) { const float2 q = a.next_pts[i]; fx = q.x; fy = q.y; }
+    int st = 1;
+    float er = 0.f;
+    float bx = 0.f, by = 0.f;
+    const int ndir = a.fb ? 2 : 1;
+    for (int dir = 0; dir < ndir; ++dir) {      // dir 1 = backward pass from the forward result
+        const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
+        const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
+        const int sa = (dir ? a.slot_b : a.slot_a) + idx, sb = (dir ? a.slot_a : a.slot_b) + idx;
+        float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
+        float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
+        int s = 1;
+        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny);
+        if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
+        else { bx = ox; by = oy; }
+    }
+    if (a.fb) {
+        const float dx = fabsf(p.x - bx), dy = fabsf(p.y - by);
+        float d = dx > dy ? dx : dy;
+        if (dx != dx || dy != dy) d = __builtin_nanf("");
+        st = st & (d < a.fb_thresh ? 1 : 0);
+    }
+    if (lane == 0) {
+        a.next_pts[i] = make_float2(fx, fy);
+        a.status[i] = (uint8_t)st;
+        a.err[i] = er;
+    }
+}
+
+template <int R>
+void launch_r(const LKArgs& a, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL(lk_track_kernel<R>, dim3(a.n), dim3(64), lds_bytes, st, a);
+}
+
+}  // namespace
+
+int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                   int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                   uint8_t* d_status, float* d_err, int n, int max_count, double eps2, int flags,
+                   float min_eig_thr, int fb, float fb_thresh) {
+    LKArgs a;
+    a.lv_a = prev->d_lv; a.lv_b = next->d_lv;
+    a.n_levels = prev->levels;
+    a.slot_a = prev_slot; a.slot_b = next_slot;
+    a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
+    a.img_idx = d_img_idx;
+    a.next_pts = reinterpret_cast<float2*>(d_next_pts);
+    a.status = d_status; a.err = d_err; a.n = n;
+    a.win_w = prev->win_w; a.win_h = prev->win_h;
+    if (a.win_w > 64) { vofe_set_error("vofe_lk_track: winSize.width %d > 64 is not supported", a.win_w); return VOFE_E_UNSUPPORTED; }
+    a.groups = 64 / a.win_w;
+    if (a.groups > a.win_h) a.groups = a.win_h;
+    a.rows_per_group = (a.win_h + a.groups - 1) / a.groups;
+    if (a.rows_per_group > 64) { vofe_set_error("vofe_lk_track: winSize %dx%d too tall (max 64 rows per lane)", a.win_w, a.win_h); return VOFE_E_UNSUPPORTED; }
+    a.max_count = max_count; a.flags = flags; a.fb = fb;
+    a.min_eig_thr = min_eig_thr; a.fb_thresh = fb_thresh; a.eps2 = eps2;
+    a.rw = a.win_w + 1 + 2 * LK_MARGIN; a.rh = a.win_h + 1 + 2 * LK_MARGIN;
+    const size_t lds_bytes = (size_t)a.rw * a.rh * 4;
+    const int R = a.rows_per_group;
+    hipStream_t st = ctx->stream;
+    if (R <= 2) launch_r<2>(a, lds_bytes, st);
+    else if (R <= 3) launch_r<3>(a, lds_bytes, st);
+    else if (R <= 4) launch_r<4>(a, lds_bytes, st);
+    else if (R <= 7) launch_r<7>(a, lds_bytes, st);
+    else if (R <= 12) launch_r<12>(a, lds_bytes, st);
+    else if (R <= 16) launch_r<16>(a, lds_bytes, st);
+    else if (R <= 24) launch_r<24>(a, lds_bytes, st);
+    else if (R <= 32) launch_r<32>(a, lds_bytes, st);
+    else if (R <= 41) launch_r<41>(a, lds_bytes, st);
+    else launch_r<64>(a, lds_bytes, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vofe_hip_fail(e, "lk_track launch");
+    return VOFE_OK;
+}

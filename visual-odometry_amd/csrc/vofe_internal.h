@@ -1,0 +1,71 @@
+// Internal declarations shared by the HIP translation units of libvofe.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <climits>
+
+#include "../../include/vofe.h"
+
+#define VOFE_MAX_LEVELS 16
+
+// One pyramid level as the kernels see it.  I/D point at pixel (0,0) of slot 0; D packs
+// (Ix | Iy << 16) per pixel.  pitch is in pixels for both planes (I: bytes, D: 4-byte units).
+struct VofeLevel {
+    uint8_t* I;
+    int* D;
+    int w, h;
+    int pitch;
+    int rows;                 // h + 2*pad_y
+    long long slot_stride;    // pixels between consecutive slots (same for I and D)
+};
+
+struct vofe_ctx {
+    int device;
+    hipStream_t stream;
+    // GFTT workspace (grown on demand)
+    void* ws;
+    size_t ws_bytes;
+    int* h_pinned;            // small pinned readback buffer
+    size_t h_pinned_ints;
+};
+
+struct vofe_pyr {
+    int slots, height, width, win_w, win_h, levels, with_deriv;
+    int pad_x, pad_y;
+    VofeLevel lv[VOFE_MAX_LEVELS];     // host copy
+    VofeLevel* d_lv;                   // device copy (levels entries)
+    uint8_t* d_I;                      // allocation bases
+    int* d_D;
+};
+
+void vofe_set_error(const char* fmt, ...);
+int vofe_hip_fail(hipError_t e, const char* what);
+
+#define VOFE_HIP(call)                                              \
+    do {                                                            \
+        hipError_t e_ = (call);                                     \
+        if (e_ != hipSuccess) return vofe_hip_fail(e_, #call);      \
+    } while (0)
+
+// kernels' host launchers (each returns VOFE_OK or an error code after hipGetLastError)
+int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, const uint8_t* d_img,
+                        int pitch, size_t img_stride);
+int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
+                   int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                   uint8_t* d_status, float* d_err, int n, int max_count, double eps2, int flags,
+                   float min_eig_thr, int fb, float fb_thresh);
+int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
+                             size_t img_stride, int harris, float k, float* d_score,
+                             unsigned* d_max_keys, const uint8_t* d_mask);
+int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
+                   size_t img_stride, int max_corners, double quality, double min_distance,
+                   const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
+                   int* h_n_out);
+
+// ---- device helpers shared by kernels ------------------------------------------------------
+__device__ __forceinline__ int vofe_reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
+    return p;
+}

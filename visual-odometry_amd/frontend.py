@@ -1,0 +1,266 @@
+"""Host-side mirror of the three cv2 calls on the reference's hot path, backed by libvofe.so.
+
+Same names, argument meaning, return shapes and error behaviour as the calls at reference
+continuous.py:145-151 / 380-385 and initialization.py:41-52:
+
+    goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, ...) -> (N,1,2) f32 | None
+    calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria, flags,
+                         minEigThreshold) -> (nextPts (N,1,2) f32, status (N,1) u8, err (N,1) f32)
+    track_keypoints(prev_keypoints (2,N), img_prev, img_current) -> ((2,N) f32, (N,) u8, (N,) f32)
+        twin of ContinuousVO._track_keypoints (continuous.py:116-164)
+
+torch is used only to own device memory and the stream; all compute is in the HIP library.
+Images may be numpy uint8 (H,W) arrays (copied to the device per call) or CUDA uint8 tensors
+(used in place).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import error
+
+TERM_CRITERIA_COUNT = 1
+TERM_CRITERIA_EPS = 2
+OPTFLOW_USE_INITIAL_FLOW = 4
+OPTFLOW_LK_GET_MIN_EIGENVALS = 8
+
+_DEFAULT_CRITERIA = (TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01)
+
+
+class Pyramid:
+    """A vofe_pyr: `slots` images of one geometry, all levels + Scharr planes resident in HBM."""
+
+    def __init__(self, fe, slots, height, width, winSize, maxLevel, with_deriv=True):
+        self.fe = fe
+        self.slots, self.height, self.width = int(slots), int(height), int(width)
+        self.winSize, self.maxLevel = (int(winSize[0]), int(winSize[1])), int(maxLevel)
+        self._h = C.c_void_p()
+        _lib.check(fe.L.vofe_pyramid_create(fe.ctx, self.slots, self.height, self.width, self.winSize[0],
+                                            self.winSize[1], self.maxLevel, int(bool(with_deriv)),
+                                            C.byref(self._h)))
+        self.levels = fe.L.vofe_pyramid_levels(self._h)
+
+    def build(self, images, slot0=0):
+        """images: CUDA uint8 tensor (H,W) or (B,H,W); fills slots slot0..slot0+B-1 (asynchronous)."""
+        t = images if images.dim() == 3 else images.unsqueeze(0)
+        if t.dtype != torch.uint8 or not t.is_cuda or t.shape[1] != self.height or t.shape[2] != self.width:
+            raise error(-1, "Pyramid.build: need CUDA uint8 images of %dx%d" % (self.width, self.height))
+        if t.stride(2) != 1:
+            t = t.contiguous()
+        stride = t.stride(0) if t.shape[0] > 1 else 0
+        _lib.check(self.fe.L.vofe_pyramid_build(self.fe.ctx, self._h, int(slot0), int(t.shape[0]), t.data_ptr(),
+                                                int(t.stride(1)), int(stride)))
+        self._keep = t          # keep the source alive until the stream has consumed it
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _lib.check(self.fe.L.vofe_pyramid_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return h.value, w.value
+
+    def download(self, slot, level, deriv=False):
+        h, w = self.level_size(level)
+        img = np.empty((h, w), np.uint8)
+        d = np.empty((h, w, 2), np.int16) if deriv else None
+        _lib.check(self.fe.L.vofe_pyramid_download(self.fe.ctx, self._h, slot, level, img.ctypes.data,
+                                                   d.ctypes.data if deriv else None))
+        return (img, d) if deriv else img
+
+    def download_padded(self, slot, level, pad=None):
+        px, py = self.winSize if pad is None else pad
+        h, w = self.level_size(level)
+        img = np.empty((h + 2 * py, w + 2 * px), np.uint8)
+        _lib.check(self.fe.L.vofe_pyramid_download_padded(self.fe.ctx, self._h, slot, level, px, py, img.ctypes.data))
+        return img
+
+    def free(self):
+        if self._h:
+            self.fe.L.vofe_pyramid_free(self.fe.ctx, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FrontEnd:
+    """One context = one GPU + one stream (the current torch stream of `device` at construction)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("visual-odometry_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.ctx = C.c_void_p()
+        _lib.check(self.L.vofe_create(int(device), C.c_void_p(self.stream.cuda_stream), C.byref(self.ctx)))
+        self._pyr_cache = {}
+
+    def close(self):
+        for p in self._pyr_cache.values():
+            p.free()
+        self._pyr_cache = {}
+        if self.ctx:
+            self.L.vofe_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self.L.vofe_synchronize(self.ctx))
+
+    # -------------------------------------------------------------------------------- helpers
+    def to_device(self, img):
+        if isinstance(img, torch.Tensor):
+            if img.dtype != torch.uint8 or img.dim() != 2:
+                raise error(-1, "image must be a single-channel 8-bit (H,W) array")
+            return img.to(self.device)
+        a = np.asarray(img)
+        if a.dtype != np.uint8 or a.ndim != 2:
+            raise error(-1, "image must be a single-channel 8-bit (H,W) array")
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=False)
+
+    def pyramid(self, slots, height, width, winSize, maxLevel):
+        key = (int(slots), int(height), int(width), int(winSize[0]), int(winSize[1]), int(maxLevel))
+        p = self._pyr_cache.get(key)
+        if p is None:
+            p = Pyramid(self, slots, height, width, winSize, maxLevel, True)
+            self._pyr_cache[key] = p
+        return p
+
+    @staticmethod
+    def _points(prevPts):
+        p = np.asarray(prevPts)
+        if p.dtype != np.float32 or p.size % 2 != 0 or (p.ndim and p.shape[-1] != 2):
+            raise error(-1, "prevPts must be an (N,1,2) or (N,2) float32 array")   # cv2: checkVector(2, CV_32F)
+        return np.ascontiguousarray(p.reshape(-1, 2))
+
+    # -------------------------------------------------------------------------------- cv2 twins
+    def calcOpticalFlowPyrLK(self, prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
+                             criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
+        a, b = self.to_device(prevImg), self.to_device(nextImg)
+        if a.shape != b.shape:
+            raise error(-1, "prevImg and nextImg must have the same size")
+        p = self._points(prevPts)
+        n = p.shape[0]
+        if n == 0:
+            return None, None, None
+        pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
+        pyr.build(torch.stack([a, b]), 0)
+        d_prev = torch.from_numpy(p).to(self.device)
+        if flags & OPTFLOW_USE_INITIAL_FLOW:
+            q = self._points(nextPts)
+            if q.shape != p.shape:
+                raise error(-1, "nextPts must match prevPts with OPTFLOW_USE_INITIAL_FLOW")
+            d_next = torch.from_numpy(q).to(self.device)
+        else:
+            d_next = torch.empty_like(d_prev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=self.device)
+        d_err = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, d_next.data_ptr(),
+                                        d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
+                                        float(criteria[2]), int(flags), float(minEigThreshold)))
+        return (d_next.cpu().numpy().reshape(-1, 1, 2), d_st.cpu().numpy().reshape(-1, 1),
+                d_err.cpu().numpy().reshape(-1, 1))
+
+    def track_keypoints(self, prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,
+                        criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3, fb_thresh=1.0):
+        """ContinuousVO._track_keypoints (continuous.py:116-164): forward + backward LK + FB check."""
+        prev_keypoints = np.asarray(prev_keypoints)
+        if prev_keypoints.size == 0:                                   # continuous.py:131-132
+            return np.empty((2, 0)), np.empty((0,), dtype=np.uint8), np.empty((0,), dtype=np.float32)
+        a, b = self.to_device(img_prev), self.to_device(img_current)
+        if a.shape != b.shape:
+            raise error(-1, "img_prev and img_current must have the same size")
+        p = np.ascontiguousarray(prev_keypoints.T.reshape(-1, 2).astype(np.float32))      # continuous.py:134-135
+        n = p.shape[0]
+        pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
+        pyr.build(torch.stack([a, b]), 0)
+        d_prev = torch.from_numpy(p).to(self.device)
+        d_next = torch.empty_like(d_prev)
+        d_st = torch.empty(n, dtype=torch.uint8, device=self.device)
+        d_err = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, d_next.data_ptr(),
+                                        d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
+                                        float(criteria[2]), float(minEigThreshold), float(fb_thresh)))
+        return d_next.cpu().numpy().T, d_st.cpu().numpy(), d_err.cpu().numpy()
+
+    def corner_score(self, image, useHarrisDetector=False, k=0.04, blockSize=3, ksize=3):
+        a = self.to_device(image)
+        out = torch.empty(a.shape, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.vofe_corner_score(self.ctx, a.data_ptr(), 1, a.shape[0], a.shape[1], a.stride(0), 0,
+                                            int(blockSize), int(ksize), int(bool(useHarrisDetector)), float(k),
+                                            out.data_ptr()))
+        return out.cpu().numpy()
+
+    def goodFeaturesToTrack(self, image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
+                            useHarrisDetector=False, k=0.04, gradientSize=3):
+        a = self.to_device(image)
+        h, w = a.shape
+        cap = int(maxCorners) if maxCorners > 0 else h * w
+        d_mask = None
+        if mask is not None:
+            d_mask = self.to_device(mask).contiguous()
+            if d_mask.shape != a.shape:
+                raise error(-1, "mask must be 8-bit and match the image size")
+        out = torch.empty((max(cap, 1), 2), dtype=torch.float32, device=self.device)
+        n = C.c_int(0)
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        _lib.check(self.L.vofe_gftt(self.ctx, a.data_ptr(), h, w, a.stride(0), int(maxCorners), float(qualityLevel),
+                                    float(minDistance), d_mask.data_ptr() if d_mask is not None else None,
+                                    int(blockSize), int(gradientSize), int(bool(useHarrisDetector)), float(k),
+                                    out.data_ptr(), cap, C.byref(n)))
+        if n.value == 0:
+            return None
+        return out[: n.value].cpu().numpy().reshape(-1, 1, 2)
+
+    def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
+                                  k=0.04):
+        """images: CUDA uint8 (B,H,W).  Returns (corners CUDA f32 (B,maxCorners,2), counts list)."""
+        if maxCorners <= 0:
+            raise error(-1, "batched detection needs maxCorners > 0")
+        t = images.contiguous()
+        B, h, w = t.shape
+        out = torch.empty((B, int(maxCorners), 2), dtype=torch.float32, device=self.device)
+        cnt = (C.c_int * B)()
+        _lib.check(self.L.vofe_gftt_batch(self.ctx, t.data_ptr(), B, h, w, w, h * w, int(maxCorners),
+                                          float(qualityLevel), float(minDistance), 3, 3,
+                                          int(bool(useHarrisDetector)), float(k), out.data_ptr(), int(maxCorners), cnt))
+        return out, list(cnt)
+
+
+_default = None
+
+
+def default_frontend():
+    global _default
+    if _default is None:
+        _default = FrontEnd(0)
+    return _default
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
+                        useHarrisDetector=False, k=0.04):
+    return default_frontend().goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
+                                                  useHarrisDetector, k)
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
+                         criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
+    return default_frontend().calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria,
+                                                   flags, minEigThreshold)
+
+
+def track_keypoints(prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,
+                    criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3):
+    return default_frontend().track_keypoints(prev_keypoints, img_prev, img_current, winSize, maxLevel, criteria,
+                                              minEigThreshold)
