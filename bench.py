@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the feature front end's LK frame on MI355X (BASELINE.json configs[1]).
+
+One step = one "LK frame"  on a synthetic KITTI-shaped pair: Gaussian pyramids +
+Scharr planes of BOTH 1241x376 frames, forward LK of 2000 keypoints (21x21 window, 4 levels,
+criteria (30, 0.01), minEigThreshold 1e-3), backward LK from every forward result and the
+forward-backward check -- exactly what ContinuousVO._track_keypoints asks of cv2 per call
+(reference continuous.py:131-164).  Inputs (8 frames, point sets) are resident in HBM before the
+timed region; every step goes through the C ABI (libvofe.so).  N > 1: each rank tracks its own
+independent sequence (seed 100 + rank) -- replicas only, no collective on the data path.
+
+Prints ONE JSON line on rank 0 (see the driver contract): metric / value (whole-job frames/s) /
+roofline (dominant kernel lk_track_kernel, HIP-event timed inside the timed region) /
+cpu_baseline (the CPU oracle, a port, timed on the host cores of this box on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+WIN = (21, 21)
+MAX_LEVEL = 3
+CRITERIA = (3, 30, 0.01)
+MIN_EIG = 1e-3
+N_FRAMES = 8
+
+
+def lk_algorithmic_bytes(win, point_levels, iterations):
+    """per point-level (w+1)^2 * (1 + 4) B of template patch, plus (w+1)^2 B of
+    search-image window per Gauss-Newton iteration."""
+    px = (win[0] + 1) * (win[1] + 1)
+    return point_levels * px * 5 + iterations * px
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--points", type=int, default=2000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from visual_odometry_amd import synthetic, _lib
+    from visual_odometry_amd.frontend import FrontEnd, Pyramid
+    H, W, _, _, _, _ = synthetic.CONFIGS["kitti"]
+    fe = FrontEnd(local_rank)
+    L = fe.L
+    dev = fe.device
+
+    # ---- inputs, resident in HBM ------------------------------------------------------------
+    seed = 0 if world == 1 else 100 + rank
+    frames = synthetic.sequence(H, W, seed=seed, n_frames=N_FRAMES)
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    pts_host = []
+    for t in range(N_FRAMES - 1):
+        c = fe.goodFeaturesToTrack(d_frames[t], args.points, 0.01, 7)
+        pts_host.append(synthetic.pad_points(c, args.points, H, W, seed + t))
+    d_pts = [torch.from_numpy(p).to(dev) for p in pts_host]
+    n = args.points
+    d_next = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_err = torch.empty(n, dtype=torch.float32, device=dev)
+    pyr = Pyramid(fe, 2, H, W, WIN, MAX_LEVEL, True)
+    d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
+    img_stride = H * W
+
+    def step(t, ev=None):
+        # reference-call-equivalent: both pyramids are rebuilt for every pair
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
+        if ev is not None:
+            ev[0].record()
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, 1, d_pts[t].data_ptr(), None, d_next.data_ptr(),
+                                   d_st.data_ptr(), d_err.data_ptr(), n, CRITERIA[0], CRITERIA[1], CRITERIA[2],
+                                   MIN_EIG, 1.0))
+        if ev is not None:
+            ev[1].record()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i % (N_FRAMES - 1))
+    # tracked keypoints per frame pair (status == 1 after the forward-backward check), untimed
+    tracked = []
+    for t in range(N_FRAMES - 1):
+        step(t)
+        tracked.append(int(d_st.sum().item()))
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    _lib.check(L.vofe_lk_set_counters(fe.ctx, d_cnt.data_ptr()))
+    d_cnt.zero_()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i % (N_FRAMES - 1), events[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    _lib.check(L.vofe_lk_set_counters(fe.ctx, None))
+    lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
+    cnt = d_cnt.cpu().numpy()
+    tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
+    tsum = float(sum(tracked_per_step))
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        agg = torch.tensor([tsum], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        tsum = float(agg.item())
+
+    frames_total = args.steps * world
+    fps = frames_total / elapsed
+
+    out = None
+    if rank == 0:
+        launches = max(args.steps, 1)
+        alg_bytes = lk_algorithmic_bytes(WIN, float(cnt[1]), float(cnt[2])) / launches
+        achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int32 bilinear + int64 window sums, f32 2x2 solve",
+            "data": "synthetic (seeded band-limited texture, KITTI-like warp + N(0,1.5) noise; SURVEY 8d)",
+            "config": {"workload": "BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
+                                   "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
+                                   "reference-call-equivalent (both pyramids rebuilt per pair)" % n,
+                       "frames_per_step": 1, "points": n, "sequences": world, "parallelism": "replicas only (one sequence per GPU)"},
+            "tracked_keypoints_per_s": round(tsum / elapsed, 1),
+            "attempted_points_per_s": round(frames_total * n / elapsed, 1),
+            "roofline": {
+                "kernel": "lk_track_kernel<7> (fwd + bwd + FB check in one launch)",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / PEAK_HBM_GBS, 5),
+                "traffic": None,
+                "avg_launch_ms": round(lk_ms, 5),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "point_levels_per_launch": float(cnt[1]) / launches,
+                "gn_iterations_per_launch": float(cnt[2]) / launches,
+                "note": "gather + VALU + LDS bound (SURVEY 8d): patches are L2/LDS resident, so the HBM fraction is "
+                        "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2",
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(frames, pts_host, args.cpu_seconds)
+    fe.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(frames, pts, seconds):
+    """The CPU oracle (a port of the OpenCV path, kind 'port') on this box's host cores, same workload,
+    bounded sample.  Reported beside the GPU number; it is not the thing measured above."""
+    import oracle
+    threads = max(1, min(16, os.cpu_count() or 1))
+
+    def run(nthreads, budget):
+        done, t0 = 0, time.perf_counter()
+        while True:
+            t = done % (len(frames) - 1)
+            oracle.track_keypoints(pts[t].T, frames[t], frames[t + 1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, nthreads)
+            done += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget and done >= 3:
+                return done / dt, done
+    oracle.track_keypoints(pts[0].T, frames[0], frames[1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, threads)   # warm-up
+    fps_mt, n_mt = run(threads, seconds * 0.6)
+    fps_1, n_1 = run(1, seconds * 0.4)
+    return {"value": round(fps_mt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d LK frames of the same workload (oracle/vofe_oracle.cpp, std::thread over points)" % n_mt,
+            "single_thread_value": round(fps_1, 3), "single_thread_sample_frames": n_1,
+            "host_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,11 @@ int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
                   double min_eig_thr, float fb_thresh);
 
+/* Measurement aid (no counterpart in the reference): when d_counters is non-NULL every later LK
+ * launch of this ctx adds {points, point-levels entered, Gauss-Newton iterations} to the three
+ * device uint64 words at d_counters (both passes of vofe_track_fb count).  NULL switches it off. */
+int vofe_lk_set_counters(vofe_ctx* ctx, unsigned long long* d_counters);
+
 /* ---- corner detection --------------------------------------------------------------------------
  * vofe_corner_score replaces cv::cornerMinEigenVal / cv::cornerHarris (blockSize 3, Sobel
  * aperture 3) that cv2.goodFeaturesToTrack runs at reference continuous.py:380-385 and

@@ -11,7 +11,14 @@ F32 = np.float32
 
 
 def _pad101(a, p):
-    return np.pad(a, p, mode="reflect") if min(a.shape) > 1 else np.pad(a, p, mode="edge")
+    """REFLECT_101 padding of the first two axes; an axis of length 1 repeats its only element."""
+    if np.isscalar(p):
+        p = ((p, p), (p, p))
+    for ax in (0, 1):
+        w = [(0, 0)] * a.ndim
+        w[ax] = tuple(p[ax])
+        a = np.pad(a, w, mode="reflect" if a.shape[ax] > 1 else "edge")
+    return a
 
 
 def pyr_down(img):

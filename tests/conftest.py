@@ -19,3 +19,5 @@ def fe():
     f = FrontEnd(0)
     yield f
     f.close()
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,23 @@
+"""Writes tests/golden/frontend_small.npz from the CPU oracle (NOT from cv2: cv2 is absent from the
+image and the reference ships no fixtures).  Inputs are seeded synthetic frames;
+rerun only when the oracle's definition changes on purpose:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from visual_odometry_amd import synthetic  # noqa: E402
+
+a, b = synthetic.sequence(48, 64, seed=123, n_frames=2)
+corners = oracle.goodFeaturesToTrack(a, 32, 0.01, 5)
+pts = synthetic.pad_points(corners, 32, 48, 64, 123)
+n, s, e = oracle.calcOpticalFlowPyrLK(a, b, pts, None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
+t, fs, fe = oracle.track_keypoints(pts.T, a, b, (11, 11), 2)
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "frontend_small.npz"),
+                    img0=a, img1=b, pyr1=oracle.pyr_down(a), scharr0=oracle.scharr(a), score=oracle.corner_score(a),
+                    harris=oracle.corner_score(a, True), corners=corners, pts=pts, lk_next=n, lk_status=s, lk_err=e,
+                    fb_next=t, fb_status=fs, fb_err=fe)
+print("written", len(pts), "points,", corners.shape[0], "corners")

@@ -111,6 +111,32 @@ def test_lk_out_of_bounds_flat_and_wild_points(fe):
     assert s1.sum() == 0                     # flat patch fails the minEig test
 
 
+def test_lk_negative_fourth_bilinear_weight(fe):
+    """16384 - w00 - w01 - w10 == -1 for ~1e-5 of sub-pixel positions: must be handled as signed."""
+    from test_oracle_cpu import negative_weight_points
+    a, b = _seq(120, 160, 3)
+    pts = np.concatenate([negative_weight_points(8, 40.0, 40.0), negative_weight_points(8, 90.0, 70.0)])
+    for lvl in (0, 2):
+        exact, _, st = _lk_compare(fe, a, b, pts, (21, 21), lvl)
+        assert exact and st.sum() > 0
+    exact, _, _ = _lk_compare(fe, b, a, pts, (21, 21), 0)
+    assert exact
+
+
+def test_lk_counters(fe):
+    import torch
+    from visual_odometry_amd import _lib
+    a, b = _seq(120, 160, 3)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 100, 0.01, 7), 100, 120, 160, 3)
+    cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+    _lib.check(fe.L.vofe_lk_set_counters(fe.ctx, cnt.data_ptr()))
+    fe.calcOpticalFlowPyrLK(a, b, pts, None, (21, 21), 2)
+    _lib.check(fe.L.vofe_lk_set_counters(fe.ctx, None))
+    fe.calcOpticalFlowPyrLK(a, b, pts, None, (21, 21), 2)
+    c = cnt.cpu().numpy()
+    assert c[0] == 100 and 100 <= c[1] <= 300 and c[1] <= c[2] <= 30 * c[1]
+
+
 def test_lk_recovers_known_flow(fe):
     h, w = 376, 1241
     f = synthetic.sequence(h, w, seed=0, n_frames=2, noise_sigma=0.0)

@@ -1,0 +1,90 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/vofe.h
+declares (no compute calls without a GPU), the product path fails loudly without a GPU, and the
+FrameState / preset mirrors keep the reference's contract."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vofe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vofe_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from visual_odometry_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libvofe.so missing: run __graft_entry__.build()"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(L, name), "libvofe.so does not export %s" % name
+    assert sorted(_lib.SYMBOLS) == declared
+    L.vofe_version.restype = ctypes.c_int
+    assert L.vofe_version() == 100
+    L.vofe_last_error.restype = ctypes.c_char_p
+    assert isinstance(L.vofe_last_error(), bytes)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from visual_odometry_amd import _lib
+    L = _lib.load()
+    ctx = ctypes.c_void_p()
+    rc = L.vofe_create(0, None, ctypes.byref(ctx))
+    assert rc != 0 and not ctx.value
+    assert b"no HIP device" in L.vofe_last_error() or b"HIP error" in L.vofe_last_error()
+    from visual_odometry_amd.frontend import FrontEnd
+    with pytest.raises(RuntimeError):
+        FrontEnd(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "visual-odometry_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "vofe_cpu_" not in src, f
+
+
+def test_framestate_contract():
+    from visual_odometry_amd import FrameState
+    ok = dict(landmarks_image=np.zeros((2, 5)), landmarks_world=np.zeros((3, 5)),
+              cand_landmarks_image_current=np.zeros((2, 4)), cand_landmarks_image_first=np.zeros((2, 4)),
+              cand_landmarks_transform=np.zeros((12, 4)))
+    s = FrameState(**ok)
+    assert "5 landmarks" in str(s) and "4 candidate" in str(s)
+    FrameState(**{**ok, "cand_landmarks_transform": np.zeros((16, 4))})
+    for key, bad in (("landmarks_image", np.zeros((3, 5))), ("landmarks_world", np.zeros((3, 6))),
+                     ("cand_landmarks_image_current", np.zeros((2, 3))), ("cand_landmarks_image_first", np.zeros(4)),
+                     ("cand_landmarks_transform", np.zeros((13, 4)))):
+        with pytest.raises(ValueError):
+            FrameState(**{**ok, key: bad})
+
+
+def test_presets_match_reference_tables():
+    from visual_odometry_amd import TRACKING_PRESETS, BOOTSTRAP_PRESETS, Constants
+    assert TRACKING_PRESETS["parking"]["winSize"] == (11, 11) and TRACKING_PRESETS["kitti"]["winSize"] == (21, 21)
+    assert all(p["maxLevel"] == 3 and p["minEigThreshold"] == 0.001 for p in TRACKING_PRESETS.values())
+    assert BOOTSTRAP_PRESETS["malaga"]["winSize"] == (41, 41) and BOOTSTRAP_PRESETS["malaga"]["maxCorners"] == 400
+    assert all(p["maxLevel"] == 0 for p in BOOTSTRAP_PRESETS.values())
+    assert Constants.THRESHOLD_NEW_KEYPOINTS == 15
+
+
+def test_synthetic_is_seeded():
+    from visual_odometry_amd import synthetic
+    a = synthetic.sequence(40, 50, 7, 2)
+    b = synthetic.sequence(40, 50, 7, 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert a[0].dtype == np.uint8 and a[0].shape == (40, 50) and a[0].std() > 20
+    p = synthetic.pad_points(None, 100, 40, 50, 1)
+    assert p.shape == (100, 2) and p.dtype == np.float32

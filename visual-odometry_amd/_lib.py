@@ -4,14 +4,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvofe.so")
+LIB_PATH = os.environ.get("VOFE_LIB", os.path.join(_HERE, "libvofe.so"))
 
 # every symbol include/vofe.h declares (tests check the built library exports all of them)
 SYMBOLS = (
     "vofe_last_error", "vofe_version", "vofe_create", "vofe_destroy", "vofe_synchronize",
     "vofe_pyramid_create", "vofe_pyramid_free", "vofe_pyramid_build", "vofe_pyramid_levels",
     "vofe_pyramid_level_size", "vofe_pyramid_download", "vofe_pyramid_download_padded",
-    "vofe_lk_track", "vofe_track_fb", "vofe_corner_score", "vofe_gftt", "vofe_gftt_batch",
+    "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_corner_score", "vofe_gftt", "vofe_gftt_batch",
 )
 
 _lib = None
@@ -51,6 +51,7 @@ def load():
     L.vofe_pyramid_download_padded.argtypes = [vp, vp, i, i, i, i, vp]
     L.vofe_lk_track.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, i, d]
     L.vofe_track_fb.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, d, f]
+    L.vofe_lk_set_counters.argtypes = [vp, vp]
     L.vofe_corner_score.argtypes = [vp, vp, i, i, i, i, sz, i, i, i, d, vp]
     L.vofe_gftt.argtypes = [vp, vp, i, i, i, i, d, d, vp, i, i, i, d, vp, i, ip]
     L.vofe_gftt_batch.argtypes = [vp, vp, i, i, i, i, sz, i, d, d, i, i, i, d, vp, i, ip]

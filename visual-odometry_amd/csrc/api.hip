@@ -52,6 +52,7 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
     c->stream = (hipStream_t)hip_stream;
     c->ws = nullptr; c->ws_bytes = 0;
     c->h_pinned = nullptr; c->h_pinned_ints = 0;
+    c->lk_counters = nullptr;
     *out = c;
     return VOFE_OK;
 }
@@ -244,6 +245,12 @@ int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
     lk_criteria(crit_type, max_count, eps);
     return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
                           max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
+}
+
+int vofe_lk_set_counters(vofe_ctx* ctx, unsigned long long* d_counters) {
+    if (!ctx) { vofe_set_error("vofe_lk_set_counters: ctx is NULL"); return VOFE_E_ARG; }
+    ctx->lk_counters = d_counters;
+    return VOFE_OK;
 }
 
 // ------------------------------------------------------------------------------- corners

@@ -17,7 +17,10 @@
 
 namespace {
 
-constexpr int LK_MARGIN = 4;
+#ifndef LK_MARGIN_PX
+#define LK_MARGIN_PX 4
+#endif
+constexpr int LK_MARGIN = LK_MARGIN_PX;
 constexpr int W_BITS = 14;
 
 struct LKArgs {
@@ -37,6 +40,7 @@ struct LKArgs {
     float min_eig_thr, fb_thresh;
     double eps2;
     int rw, rh;                // LDS region size in pixels
+    unsigned long long* counters;   // optional {points, point-levels entered, GN iterations}
 };
 
 __device__ __forceinline__ int floor_i(float v) {
@@ -46,9 +50,11 @@ __device__ __forceinline__ int floor_i(float v) {
 }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+// signed 2-way dot product: pixel pairs (0..255) x weight pairs.  Signed on purpose: the fourth
+// bilinear weight 16384 - w00 - w01 - w10 can come out as -1 after rounding.
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), c, false);
 }
 
 // exact wave-wide sum of one int32 per lane, as int64 (all 64 lanes must be active)
@@ -78,8 +84,8 @@ __device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int 
     q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
     q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
     q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
-    q.w0 = (unsigned)q.w00 | ((unsigned)q.w01 << 16);
-    q.w1 = (unsigned)q.w10 | ((unsigned)q.w11 << 16);
+    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
+    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
     return q;
 }
 
@@ -105,7 +111,7 @@ template <int R>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* lds, int lane, int x, int y0,
-                                       int ny) {
+                                       int ny, unsigned& n_lv, unsigned& n_it) {
     const int w = a.win_w, h = a.win_h;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
@@ -127,6 +133,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
+        ++n_lv;
         // ---- template window: I, Ix, Iy at the fixed prev position -> registers
         int Ival[R], Dval[R];
         long long sA11, sA12, sA22;
@@ -147,7 +154,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int iv = (int)(udot2(pI[k], q.w0, udot2(pI[k + 1], q.w1, 256u)) >> 9);
+                const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
                 int ix = ((int)(short)dA[k] * q.w00 + (int)(short)dB[k] * q.w01 + (int)(short)dA[k + 1] * q.w10 +
                           (int)(short)dB[k + 1] * q.w11 + 8192) >> 14;
                 int iy = ((dA[k] >> 16) * q.w00 + (dB[k] >> 16) * q.w01 + (dA[k + 1] >> 16) * q.w10 +
@@ -187,6 +194,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 staged = true;
                 __syncthreads();
             }
+            ++n_it;
             const Wts q = bilinear_weights(npx, npy, inx, iny);
             const unsigned* lp = lds + (iny - ry0 + y0) * rw + (inx - rx0) + x;
             unsigned P[R + 1];
@@ -195,7 +203,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int jv = (int)(udot2(P[k], q.w0, udot2(P[k + 1], q.w1, 256u)) >> 9);
+                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
                 const int diff = jv - Ival[k];
                 b1 += diff * (int)(short)Dval[k];
                 b2 += diff * (Dval[k] >> 16);
@@ -232,7 +240,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             int se = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int jv = (int)(udot2(P[k], q.w0, udot2(P[k + 1], q.w1, 256u)) >> 9);
+                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
                 const int diff = jv - Ival[k];
                 se += (k < ny) ? abs(diff) : 0;
             }
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     float er = 0.f;
     float bx = 0.f, by = 0.f;
     const int ndir = a.fb ? 2 : 1;
+    unsigned n_lv = 0, n_it = 0;
     for (int dir = 0; dir < ndir; ++dir) {      // dir 1 = backward pass from the forward result
         const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
         const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny);
+        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny, n_lv, n_it);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
     }
@@ -283,6 +292,11 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         a.next_pts[i] = make_float2(fx, fy);
         a.status[i] = (uint8_t)st;
         a.err[i] = er;
+        if (a.counters) {
+            atomicAdd(a.counters + 0, 1ull);
+            atomicAdd(a.counters + 1, (unsigned long long)n_lv);
+            atomicAdd(a.counters + 2, (unsigned long long)n_it);
+        }
     }
 }
 
@@ -313,6 +327,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     if (a.rows_per_group > 64) { vofe_set_error("vofe_lk_track: winSize %dx%d too tall (max 64 rows per lane)", a.win_w, a.win_h); return VOFE_E_UNSUPPORTED; }
     a.max_count = max_count; a.flags = flags; a.fb = fb;
     a.min_eig_thr = min_eig_thr; a.fb_thresh = fb_thresh; a.eps2 = eps2;
+    a.counters = ctx->lk_counters;
     a.rw = a.win_w + 1 + 2 * LK_MARGIN; a.rh = a.win_h + 1 + 2 * LK_MARGIN;
     const size_t lds_bytes = (size_t)a.rw * a.rh * 4;
     const int R = a.rows_per_group;

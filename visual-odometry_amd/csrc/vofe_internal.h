@@ -28,6 +28,7 @@ struct vofe_ctx {
     size_t ws_bytes;
     int* h_pinned;            // small pinned readback buffer
     size_t h_pinned_ints;
+    unsigned long long* lk_counters;   // optional device counters (vofe_lk_set_counters)
 };
 
 struct vofe_pyr {

@@ -14,6 +14,7 @@ Images may be numpy uint8 (H,W) arrays (copied to the device per call) or CUDA u
 (used in place).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -75,9 +76,9 @@ class Pyramid:
         return img
 
     def free(self):
-        if self._h:
+        if self._h and self.fe.ctx:
             self.fe.L.vofe_pyramid_free(self.fe.ctx, self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -99,20 +100,20 @@ class FrontEnd:
         self.ctx = C.c_void_p()
         _lib.check(self.L.vofe_create(int(device), C.c_void_p(self.stream.cuda_stream), C.byref(self.ctx)))
         self._pyr_cache = {}
+        # close before interpreter teardown (HIP objects must not be freed after the runtime is gone)
+        self._fin = weakref.finalize(self, FrontEnd._finalize, self.L, self.ctx, self._pyr_cache)
+
+    @staticmethod
+    def _finalize(L, ctx, cache):
+        for p in cache.values():
+            p.free()
+        cache.clear()
+        if ctx:
+            L.vofe_destroy(ctx)
+            ctx.value = None
 
     def close(self):
-        for p in self._pyr_cache.values():
-            p.free()
-        self._pyr_cache = {}
-        if self.ctx:
-            self.L.vofe_destroy(self.ctx)
-            self.ctx = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        self._fin()
 
     def synchronize(self):
         _lib.check(self.L.vofe_synchronize(self.ctx))

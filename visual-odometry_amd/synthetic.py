@@ -57,7 +57,7 @@ def pad_points(corners, n, h, w, seed):
     """detected corners padded to n with uniform-random f32 positions, ~2 % of all points
     within 10 px of the border (exercises the out-of-bounds branches)."""
     rng = np.random.default_rng(seed + 7919)
-    pts = np.zeros((0, 2), np.float32) if corners is None else np.asarray(corners, np.float32).reshape(-1, 2)
+    pts = np.zeros((0, 2), np.float32) if corners is None else np.array(corners, np.float32).reshape(-1, 2)
     pts = pts[:n]
     short = n - len(pts)
     if short > 0:
