@@ -112,9 +112,15 @@ def main():
     for t in range(N_FRAMES - 1):
         step(t)
         tracked.append(int(d_st.sum().item()))
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # work counters of the LK launches (point-levels, Gauss-Newton iterations): one untimed pass over the
+    # pairs, because the counting atomics would slow the timed launches
     _lib.check(L.vofe_lk_set_counters(fe.ctx, d_cnt.data_ptr()))
-    d_cnt.zero_()
+    for t in range(N_FRAMES - 1):
+        step(t)
+    torch.cuda.synchronize()
+    _lib.check(L.vofe_lk_set_counters(fe.ctx, None))
+    cnt_pair = d_cnt.cpu().numpy().astype(np.float64) / (N_FRAMES - 1)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     barrier()
     t0 = time.perf_counter()
@@ -123,9 +129,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    _lib.check(L.vofe_lk_set_counters(fe.ctx, None))
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
-    cnt = d_cnt.cpu().numpy()
     tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
     tsum = float(sum(tracked_per_step))
 
@@ -142,8 +146,7 @@ def main():
 
     out = None
     if rank == 0:
-        launches = max(args.steps, 1)
-        alg_bytes = lk_algorithmic_bytes(WIN, float(cnt[1]), float(cnt[2])) / launches
+        alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_pair[1]), float(cnt_pair[2]))
         achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         out = {
             "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",
@@ -174,8 +177,8 @@ def main():
                 "traffic": None,
                 "avg_launch_ms": round(lk_ms, 5),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
-                "point_levels_per_launch": float(cnt[1]) / launches,
-                "gn_iterations_per_launch": float(cnt[2]) / launches,
+                "point_levels_per_launch": float(cnt_pair[1]),
+                "gn_iterations_per_launch": float(cnt_pair[2]),
                 "note": "gather + VALU + LDS bound (SURVEY 8d): patches are L2/LDS resident, so the HBM fraction is "
                         "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2",
             },

@@ -39,7 +39,8 @@ struct LKArgs {
     int max_count, flags, fb;
     float min_eig_thr, fb_thresh;
     double eps2;
-    int rw, rh;                // LDS region size in pixels
+    int rh, rs;                // LDS region: rows, row stride in entries (8 * segs)
+    int segs, inv_segs;        // 8-entry segments per row; (t * inv_segs) >> 20 == t / segs for all tasks
     unsigned long long* counters;   // optional {points, point-levels entered, GN iterations}
 };
 
@@ -89,21 +90,73 @@ __device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int 
     return q;
 }
 
-// stage the (rw x rh) region of J whose top-left pixel is (rx0, ry0) as (J[x] | J[x+1]<<16)
-__device__ __forceinline__ void stage_region(unsigned* lds, const uint8_t* __restrict__ J0, const VofeLevel& B,
-                                             int win_w, int win_h, int rx0, int ry0, int rw, int rh, int lane) {
-    const int xmin = -win_w, xmax = B.w + win_w - 1, ymin = -win_h, ymax = B.h + win_h - 1;
-    int cx = lane % rw, cy = lane / rw;
-    const int sx = 64 % rw, sy = 64 / rw;
-    const int total = rw * rh;
-    for (int e = lane; e < total; e += 64) {
-        const int gy = min(max(ry0 + cy, ymin), ymax);
-        const int gxa = min(max(rx0 + cx, xmin), xmax);
-        const int gxb = min(max(rx0 + cx + 1, xmin), xmax);
-        const uint8_t* r = J0 + (long long)gy * B.pitch;
-        lds[e] = (unsigned)r[gxa] | ((unsigned)r[gxb] << 16);
-        cx += sx; cy += sy;
-        if (cx >= rw) { cx -= rw; ++cy; }
+// Explicit global-address-space loads at byte alignment: the plane pointers come out of a table in
+// memory, so without the cast the compiler has to emit flat_load (which also ties up lgkmcnt).
+#define VOFE_GLOBAL __attribute__((address_space(1)))
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((aligned(1))) u32x2_unaligned;
+typedef unsigned short __attribute__((aligned(1))) u16_unaligned;
+__device__ __forceinline__ uint2 gload_u64(const void* p) {
+    const u32x2 v = *((const VOFE_GLOBAL u32x2_unaligned*)p);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned gload_u16(const void* p) { return *((const VOFE_GLOBAL u16_unaligned*)p); }
+__device__ __forceinline__ unsigned gload_u8(const void* p) { return *((const VOFE_GLOBAL uint8_t*)p); }
+
+// ---- staging of the search image J into LDS -------------------------------------------------
+// LDS image: rh rows x rs entries (rs = 8 * segs >= rw), entry = J[x] | J[x+1] << 16, top-left pixel
+// (rx0, ry0).  One task = one row x 8 entries = 9 consecutive bytes of J (an unaligned 8-byte load
+// plus one byte); a lane runs up to ST_BATCH tasks per batch with all loads issued before the first
+// LDS write, so a staging pass costs one memory latency, not one per task.
+constexpr int ST_BATCH = 4;
+struct StageRegs { uint2 v[ST_BATCH]; unsigned nb[ST_BATCH]; };
+
+__device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_h,
+                                           int rx0, int ry0, int segs, int inv_segs, int tasks, int t0, int lane) {
+    const int ymin = -win_h, ymax = B.h + win_h - 1;
+#pragma unroll
+    for (int k = 0; k < ST_BATCH; ++k) {
+        const int t = t0 + k * 64 + lane;
+        const int row = (int)(((unsigned)t * (unsigned)inv_segs) >> 20);
+        const int seg = t - row * segs;
+        s.v[k] = make_uint2(0u, 0u);
+        s.nb[k] = 0u;
+        if (t < tasks) {
+            const int gy = min(max(ry0 + row, ymin), ymax);
+            const uint8_t* p = J0 + (long long)gy * B.pitch + (rx0 + seg * 8);
+            s.v[k] = gload_u64(p);
+            s.nb[k] = gload_u8(p + 8);
+        }
+    }
+}
+__device__ __forceinline__ void stage_write(const StageRegs& s, unsigned* lds, int segs, int inv_segs, int tasks, int t0,
+                                            int lane) {
+#pragma unroll
+    for (int k = 0; k < ST_BATCH; ++k) {
+        const int t = t0 + k * 64 + lane;
+        if (t < tasks) {
+            const unsigned lo = s.v[k].x, hi = s.v[k].y, nb = s.nb[k];
+            uint4 a, b;
+            a.x = __builtin_amdgcn_perm(0u, lo, 0x0c010c00u);
+            a.y = __builtin_amdgcn_perm(0u, lo, 0x0c020c01u);
+            a.z = __builtin_amdgcn_perm(0u, lo, 0x0c030c02u);
+            a.w = __builtin_amdgcn_perm(hi, lo, 0x0c040c03u);
+            b.x = __builtin_amdgcn_perm(0u, hi, 0x0c010c00u);
+            b.y = __builtin_amdgcn_perm(0u, hi, 0x0c020c01u);
+            b.z = __builtin_amdgcn_perm(0u, hi, 0x0c030c02u);
+            b.w = __builtin_amdgcn_perm(nb, hi, 0x0c040c03u);
+            uint4* d = reinterpret_cast<uint4*>(lds + t * 8);       // row * rs + seg * 8 == t * 8
+            d[0] = a; d[1] = b;
+        }
+    }
+}
+// remaining batches (windows wider than ~31 px) and re-staging after the walk left the region
+__device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_h,
+                                           int rx0, int ry0, int segs, int inv_segs, int tasks, int t_begin, int lane) {
+    for (int t0 = t_begin; t0 < tasks; t0 += 64 * ST_BATCH) {
+        StageRegs s;
+        stage_load(s, J0, B, win_h, rx0, ry0, segs, inv_segs, tasks, t0, lane);
+        stage_write(s, lds, segs, inv_segs, tasks, t0, lane);
     }
 }
 
@@ -115,7 +168,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
     const int w = a.win_w, h = a.win_h;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
-    const int rw = a.rw, rh = a.rh;
+    const int rs = a.rs, segs = a.segs, inv_segs = a.inv_segs, tasks = a.rh * a.segs;
     for (int level = top; level >= 0; --level) {
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
@@ -134,6 +187,19 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             continue;
         }
         ++n_lv;
+        // prefetch the search region around the start position (loads only; written to LDS after the
+        // template window has been computed, so both memory latencies overlap)
+        const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
+        bool staged = false;
+        int rx0 = 0, ry0 = 0;
+        StageRegs pre;
+        {
+            const int sx = floor_i(npx - hx), sy = floor_i(npy - hy);
+            if (!(sx < -w || sx >= B.w || sy < -h || sy >= B.h)) {
+                rx0 = sx - LK_MARGIN; ry0 = sy - LK_MARGIN;
+                staged = true;
+            }
+        }
         // ---- template window: I, Ix, Iy at the fixed prev position -> registers
         int Ival[R], Dval[R];
         long long sA11, sA12, sA22;
@@ -144,12 +210,15 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const int* Db = A.D + base;
             unsigned pI[R + 1];
             int dA[R + 1], dB[R + 1];
+            if (staged) stage_load(pre, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
 #pragma unroll
             for (int r = 0; r <= R; ++r) {
                 const long long off = (long long)min(r, ny) * A.pitch;
-                pI[r] = (unsigned)Ib[off] | ((unsigned)Ib[off + 1] << 16);
-                dA[r] = Db[off];
-                dB[r] = Db[off + 1];
+                const unsigned two = gload_u16(Ib + off);
+                const uint2 dd = gload_u64(Db + off);
+                pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
+                dA[r] = (int)dd.x;
+                dB[r] = (int)dd.y;
             }
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
@@ -178,9 +247,12 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         Dd = 1.f / Dd;
         npx -= hx; npy -= hy;
         float pdx = 0.f, pdy = 0.f;
-        const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
-        bool staged = false;
-        int rx0 = 0, ry0 = 0;
+        if (staged) {
+            __syncthreads();
+            stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
+            stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
+            __syncthreads();
+        }
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = floor_i(npx), iny = floor_i(npy);
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
@@ -190,16 +262,16 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_region(lds, J0, B, w, h, rx0, ry0, rw, rh, lane);
+                stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
             ++n_it;
             const Wts q = bilinear_weights(npx, npy, inx, iny);
-            const unsigned* lp = lds + (iny - ry0 + y0) * rw + (inx - rx0) + x;
+            const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
 #pragma unroll
-            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rw];
+            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rs];
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -228,15 +300,15 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_region(lds, J0, B, w, h, rx0, ry0, rw, rh, lane);
+                stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
             const Wts q = bilinear_weights(ex, ey, inx, iny);
-            const unsigned* lp = lds + (iny - ry0 + y0) * rw + (inx - rx0) + x;
+            const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
 #pragma unroll
-            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rw];
+            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rs];
             int se = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -328,8 +400,17 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     a.max_count = max_count; a.flags = flags; a.fb = fb;
     a.min_eig_thr = min_eig_thr; a.fb_thresh = fb_thresh; a.eps2 = eps2;
     a.counters = ctx->lk_counters;
-    a.rw = a.win_w + 1 + 2 * LK_MARGIN; a.rh = a.win_h + 1 + 2 * LK_MARGIN;
-    const size_t lds_bytes = (size_t)a.rw * a.rh * 4;
+    const int rw = a.win_w + 1 + 2 * LK_MARGIN;
+    a.rh = a.win_h + 1 + 2 * LK_MARGIN;
+    a.segs = (rw + 7) / 8;
+    a.rs = a.segs * 8;
+    a.inv_segs = (1 << 20) / a.segs + 1;
+    for (int t = 0; t < a.rh * a.segs; ++t)
+        if ((int)(((unsigned)t * (unsigned)a.inv_segs) >> 20) != t / a.segs) {
+            vofe_set_error("vofe_lk_track: internal reciprocal check failed");
+            return VOFE_E_UNSUPPORTED;
+        }
+    const size_t lds_bytes = (size_t)a.rs * a.rh * 4;
     const int R = a.rows_per_group;
     hipStream_t st = ctx->stream;
     if (R <= 2) launch_r<2>(a, lds_bytes, st);
