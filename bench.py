@@ -64,7 +64,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from visual_odometry_amd import synthetic, _lib
+    from visual_odometry_amd import synthetic, _lib, replicas
     from visual_odometry_amd.frontend import FrontEnd, Pyramid
     H, W, _, _, _, _ = synthetic.CONFIGS["kitti"]
     fe = FrontEnd(local_rank)
@@ -72,7 +72,7 @@ def main():
     dev = fe.device
 
     # ---- inputs, resident in HBM ------------------------------------------------------------
-    seed = 0 if world == 1 else 100 + rank
+    seed = replicas.sequence_seed(rank, world)
     frames = synthetic.sequence(H, W, seed=seed, n_frames=N_FRAMES)
     d_frames = torch.from_numpy(np.stack(frames)).to(dev)
     pts_host = []
@@ -133,13 +133,7 @@ def main():
     tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
     tsum = float(sum(tracked_per_step))
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        agg = torch.tensor([tsum], dtype=torch.float64, device=dev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        tsum = float(agg.item())
+    elapsed, (tsum,) = replicas.fold(dist, dev, elapsed, [tsum])
 
     frames_total = args.steps * world
     fps = frames_total / elapsed
