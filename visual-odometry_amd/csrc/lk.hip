@@ -13,6 +13,8 @@
 // J is staged once per level into LDS as (J[x] | J[x+1] << 16) pairs around the start position
 // (margin LK_MARGIN px) and re-staged only if the Gauss-Newton walk leaves it.  Window sums are
 // reduced with DPP row rotations + 4 readlanes.  Not HBM- or MFMA-bound: gather + VALU + LDS.
+#include <cmath>
+
 #include "vofe_internal.h"
 
 namespace {
@@ -39,6 +41,7 @@ struct LKArgs {
     int max_count, flags, fb;
     float min_eig_thr, fb_thresh;
     double eps2;
+    float eps2_lo, eps2_hi;    // f32 brackets of eps2 for the cheap convergence pre-test
     int rh, rs;                // LDS region: rows, row stride in entries (8 * segs)
     int segs, inv_segs;        // 8-entry segments per row; (t * inv_segs) >> 20 == t / segs for all tasks
     unsigned long long* counters;   // optional {points, point-levels entered, GN iterations}
@@ -71,10 +74,14 @@ __device__ __forceinline__ int wave_sum_small(int v) {                 // |sum| 
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
-__device__ __forceinline__ long long wave_sum_i64(int v) {
-    const int lo = wave_sum_small(v & 0xffff);
+// (float) of the exact 64-bit wave sum (one rounding, like the oracle's (float)int64).  The split
+// into 16-bit halves keeps every partial inside int32; when the total itself fits int32 (the
+// common case) a single v_cvt_f32_i32 replaces the 64-bit conversion sequence.
+__device__ __forceinline__ float wave_sum_to_float(int v) {
+    const int lo = wave_sum_small(v & 0xffff);            // 0 <= lo < 2^22
     const int hi = wave_sum_small(v >> 16);
-    return (long long)hi * 65536 + (long long)lo;
+    if (hi >= -32768 && hi < 32000) return (float)(hi * 65536 + lo);
+    return (float)((long long)hi * 65536 + (long long)lo);
 }
 
 struct Wts { unsigned w0, w1; int w00, w01, w10, w11; };
@@ -102,6 +109,18 @@ __device__ __forceinline__ uint2 gload_u64(const void* p) {
 }
 __device__ __forceinline__ unsigned gload_u16(const void* p) { return *((const VOFE_GLOBAL u16_unaligned*)p); }
 __device__ __forceinline__ unsigned gload_u8(const void* p) { return *((const VOFE_GLOBAL uint8_t*)p); }
+
+// Diagnostic build only (-DLK_STAMPS): s_memtime deltas per phase, written to counters[8 + 8*block + k]
+// for the first 256 blocks.  Never enabled in the shipped library.
+#ifdef LK_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = 0;
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_END(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN() do {} while (0)
+#define STAMP_END(k) do {} while (0)
+#endif
 
 // ---- staging of the search image J into LDS -------------------------------------------------
 // LDS image: rh rows x rs entries (rs = 8 * segs >= rw), entry = J[x] | J[x+1] << 16, top-left pixel
@@ -164,7 +183,9 @@ template <int R>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* lds, int lane, int x, int y0,
-                                       int ny, unsigned& n_lv, unsigned& n_it) {
+                                       int ny, unsigned& n_lv, unsigned& n_it, unsigned long long* st_acc) {
+    STAMP_DECL
+    (void)st_acc;
     const int w = a.win_w, h = a.win_h;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
@@ -187,6 +208,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             continue;
         }
         ++n_lv;
+        STAMP_BEGIN();
         // prefetch the search region around the start position (loads only; written to LDS after the
         // template window has been computed, so both memory latencies overlap)
         const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
@@ -202,14 +224,14 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         }
         // ---- template window: I, Ix, Iy at the fixed prev position -> registers
         int Ival[R], Dval[R];
-        long long sA11, sA12, sA22;
+        float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
             const long long base = (long long)slotA * A.slot_stride + (long long)(ipy + y0) * A.pitch + ipx + x;
             const uint8_t* Ib = A.I + base;
             const int* Db = A.D + base;
             unsigned pI[R + 1];
-            int dA[R + 1], dB[R + 1];
+            unsigned pX[R + 1], pY[R + 1];     // (Ix[x] | Ix[x+1] << 16), (Iy[x] | Iy[x+1] << 16)
             if (staged) stage_load(pre, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
 #pragma unroll
             for (int r = 0; r <= R; ++r) {
@@ -217,26 +239,25 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 const unsigned two = gload_u16(Ib + off);
                 const uint2 dd = gload_u64(Db + off);
                 pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
-                dA[r] = (int)dd.x;
-                dB[r] = (int)dd.y;
+                pX[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
+                pY[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
             }
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
-                int ix = ((int)(short)dA[k] * q.w00 + (int)(short)dB[k] * q.w01 + (int)(short)dA[k + 1] * q.w10 +
-                          (int)(short)dB[k + 1] * q.w11 + 8192) >> 14;
-                int iy = ((dA[k] >> 16) * q.w00 + (dB[k] >> 16) * q.w01 + (dA[k + 1] >> 16) * q.w10 +
-                          (dB[k + 1] >> 16) * q.w11 + 8192) >> 14;
+                int ix = sdot2(pX[k], q.w0, sdot2(pX[k + 1], q.w1, 8192)) >> 14;
+                int iy = sdot2(pY[k], q.w0, sdot2(pY[k + 1], q.w1, 8192)) >> 14;
                 if (k >= ny) { ix = 0; iy = 0; }
                 Ival[k] = iv;
                 Dval[k] = (ix & 0xffff) | (iy << 16);
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
             }
-            sA11 = wave_sum_i64(a11); sA12 = wave_sum_i64(a12); sA22 = wave_sum_i64(a22);
+            fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
         }
+        STAMP_END(0);
         const float FLT_SCALE = 1.f / (float)(1 << 20);
-        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        const float A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
         float Dd = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
         if (flags & 8) err = minEig;
@@ -245,6 +266,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             continue;
         }
         Dd = 1.f / Dd;
+        STAMP_END(1);
         npx -= hx; npy -= hy;
         float pdx = 0.f, pdy = 0.f;
         if (staged) {
@@ -253,6 +275,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
             __syncthreads();
         }
+        STAMP_END(2);
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = floor_i(npx), iny = floor_i(npy);
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
@@ -267,6 +290,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 __syncthreads();
             }
             ++n_it;
+            STAMP_END(6);
             const Wts q = bilinear_weights(npx, npy, inx, iny);
             const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
@@ -280,14 +304,22 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 b1 += diff * (int)(short)Dval[k];
                 b2 += diff * (Dval[k] >> 16);
             }
-            const long long sb1 = wave_sum_i64(b1), sb2 = wave_sum_i64(b2);
-            const float fb1 = (float)sb1 * FLT_SCALE, fb2 = (float)sb2 * FLT_SCALE;
+            STAMP_END(3);
+            const float fb1 = wave_sum_to_float(b1) * FLT_SCALE, fb2 = wave_sum_to_float(b2) * FLT_SCALE;
+            STAMP_END(4);
             const float dx = (A12 * fb2 - A22 * fb1) * Dd;
             const float dy = (A12 * fb1 - A11 * fb2) * Dd;
             npx += dx; npy += dy;
             outx = npx + hx; outy = npy + hy;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            STAMP_END(5);
+            // delta.ddot(delta) <= eps^2 is defined in double; an f32 pre-test (relative error < 2e-7)
+            // decides all but the borderline cases, which take the exact path
+            const float d2 = dx * dx + dy * dy;
+            bool conv = d2 < a.eps2_lo;
+            if (!conv && !(d2 > a.eps2_hi)) conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
+            if (conv) break;
+            // |(double)(float)(dx+pdx)| < 0.01  <=>  |f32 value| <= 0.01f (the largest float below 0.01)
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
             }
@@ -316,8 +348,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 const int diff = jv - Ival[k];
                 se += (k < ny) ? abs(diff) : 0;
             }
-            const long long ses = wave_sum_i64(se);
-            err = (float)ses / (float)(32 * w * h);
+            err = wave_sum_to_float(se) / (float)(32 * w * h);
         }
         __syncthreads();     // all LDS reads of this level done before the next level restages
     }
@@ -343,6 +374,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     float bx = 0.f, by = 0.f;
     const int ndir = a.fb ? 2 : 1;
     unsigned n_lv = 0, n_it = 0;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int dir = 0; dir < ndir; ++dir) {      // dir 1 = backward pass from the forward result
         const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
         const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny, n_lv, n_it);
+        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny, n_lv, n_it, st_acc);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
     }
@@ -368,6 +400,9 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
             atomicAdd(a.counters + 0, 1ull);
             atomicAdd(a.counters + 1, (unsigned long long)n_lv);
             atomicAdd(a.counters + 2, (unsigned long long)n_it);
+#ifdef LK_STAMPS
+            if (blockIdx.x < 256) for (int k = 0; k < 8; ++k) a.counters[8 + 8 * blockIdx.x + k] = st_acc[k];
+#endif
         }
     }
 }
@@ -399,6 +434,8 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     if (a.rows_per_group > 64) { vofe_set_error("vofe_lk_track: winSize %dx%d too tall (max 64 rows per lane)", a.win_w, a.win_h); return VOFE_E_UNSUPPORTED; }
     a.max_count = max_count; a.flags = flags; a.fb = fb;
     a.min_eig_thr = min_eig_thr; a.fb_thresh = fb_thresh; a.eps2 = eps2;
+    a.eps2_lo = nextafterf((float)(eps2 * (1.0 - 1e-6)), -1.f);
+    a.eps2_hi = nextafterf((float)(eps2 * (1.0 + 1e-6)), 1e30f);
     a.counters = ctx->lk_counters;
     const int rw = a.win_w + 1 + 2 * LK_MARGIN;
     a.rh = a.win_h + 1 + 2 * LK_MARGIN;
