@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--points", type=int, default=2000)
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent frame pairs in flight per GPU (one ctx + HIP stream each); 1 = strictly serial")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -81,23 +83,40 @@ def main():
         pts_host.append(synthetic.pad_points(c, args.points, H, W, seed + t))
     d_pts = [torch.from_numpy(p).to(dev) for p in pts_host]
     n = args.points
-    d_next = torch.empty((n, 2), dtype=torch.float32, device=dev)
-    d_st = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_err = torch.empty(n, dtype=torch.float32, device=dev)
-    pyr = Pyramid(fe, 2, H, W, WIN, MAX_LEVEL, True)
-    d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
     img_stride = H * W
+    d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 
-    def step(t, ev=None):
-        # reference-call-equivalent: both pyramids are rebuilt for every pair
-        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
-        if ev is not None:
-            ev[0].record()
-        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, 1, d_pts[t].data_ptr(), None, d_next.data_ptr(),
-                                   d_st.data_ptr(), d_err.data_ptr(), n, CRITERIA[0], CRITERIA[1], CRITERIA[2],
-                                   MIN_EIG, 1.0))
-        if ev is not None:
-            ev[1].record()
+    # S workers, each a ctx bound to its own HIP stream with its own pyramid object and outputs.  Frame
+    # pairs are independent (configs[1]), so pair i goes to worker i % S; inside a worker everything is
+    # in stream order.  S = 1 is the strictly serial schedule.
+    class Worker:
+        def __init__(self, stream):
+            self.stream = stream
+            with torch.cuda.stream(stream):
+                self.fe = FrontEnd(local_rank)
+                self.pyr = Pyramid(self.fe, 2, H, W, WIN, MAX_LEVEL, True)
+                self.nxt = torch.empty((n, 2), dtype=torch.float32, device=dev)
+                self.st = torch.empty(n, dtype=torch.uint8, device=dev)
+                self.err = torch.empty(n, dtype=torch.float32, device=dev)
+
+        def step(self, t, ev=None):
+            # reference-call-equivalent: both pyramids are rebuilt for every pair
+            f = self.fe
+            _lib.check(L.vofe_pyramid_build(f.ctx, self.pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
+            if ev is not None:
+                ev[0].record(self.stream)
+            _lib.check(L.vofe_track_fb(f.ctx, self.pyr._h, 0, self.pyr._h, 1, d_pts[t].data_ptr(), None,
+                                       self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
+                                       CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
+            if ev is not None:
+                ev[1].record(self.stream)
+
+    torch.cuda.synchronize()
+    workers = [Worker(torch.cuda.Stream(device=dev)) for _ in range(max(1, args.streams))]
+    S = len(workers)
+
+    def step(i, ev=None):
+        workers[i % S].step(i % (N_FRAMES - 1), ev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -106,30 +125,44 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i % (N_FRAMES - 1))
+        step(i)
     # tracked keypoints per frame pair (status == 1 after the forward-backward check), untimed
     tracked = []
     for t in range(N_FRAMES - 1):
-        step(t)
-        tracked.append(int(d_st.sum().item()))
+        workers[0].step(t)
+        workers[0].stream.synchronize()
+        tracked.append(int(workers[0].st.sum().item()))
     # work counters of the LK launches (point-levels, Gauss-Newton iterations): one untimed pass over the
     # pairs, because the counting atomics would slow the timed launches
-    _lib.check(L.vofe_lk_set_counters(fe.ctx, d_cnt.data_ptr()))
+    _lib.check(L.vofe_lk_set_counters(workers[0].fe.ctx, d_cnt.data_ptr()))
     for t in range(N_FRAMES - 1):
-        step(t)
+        workers[0].step(t)
     torch.cuda.synchronize()
-    _lib.check(L.vofe_lk_set_counters(fe.ctx, None))
+    _lib.check(L.vofe_lk_set_counters(workers[0].fe.ctx, None))
     cnt_pair = d_cnt.cpu().numpy().astype(np.float64) / (N_FRAMES - 1)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events around every EV_EVERY-th LK launch of the timed region (each record costs host time)
+    EV_EVERY = 8
+    events = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for i in range(0, args.steps, EV_EVERY)}
 
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i % (N_FRAMES - 1), events[i])
+        step(i, events.get(i))
     barrier()
     elapsed = time.perf_counter() - t0
 
-    lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
+    # the same K steps strictly serial on one stream (latency-oriented figure, reported beside value)
+    serial_ms = None
+    if S > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            workers[0].step(i % (N_FRAMES - 1))
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
+    lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
     tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
     tsum = float(sum(tracked_per_step))
 
@@ -158,7 +191,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
                                    "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
                                    "reference-call-equivalent (both pyramids rebuilt per pair)" % n,
-                       "frames_per_step": 1, "points": n, "sequences": world, "parallelism": "replicas only (one sequence per GPU)"},
+                       "frames_per_step": 1, "points": n, "sequences": world, "streams_per_gpu": S,
+                       "parallelism": "replicas only (one sequence per GPU); %d independent pairs in flight per GPU" % S},
+            "single_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
             "tracked_keypoints_per_s": round(tsum / elapsed, 1),
             "attempted_points_per_s": round(frames_total * n / elapsed, 1),
             "roofline": {
@@ -179,6 +214,9 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(frames, pts_host, args.cpu_seconds)
+    for wk in workers:
+        wk.pyr.free()
+        wk.fe.close()
     fe.close()
     if dist is not None:
         dist.barrier()
