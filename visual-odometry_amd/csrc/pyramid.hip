@@ -8,6 +8,8 @@
 // is 16-byte aligned and rows are `pitch` (multiple of 64) pixels apart.  The REFLECT_101 border
 // that OpenCV materialises with copyMakeBorder is written by the same kernel that produces the
 // interior, so pyrDown / Scharr / LK never need index arithmetic at image edges.
+#include <cstdlib>
+
 #include "vofe_internal.h"
 
 namespace {
@@ -152,6 +154,150 @@ __global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused pyramid: ONE launch produces the interiors of up to FUSE_MAX_LEVELS levels and their Scharr
+// planes.  A block owns a tw x th tile of the TOP level and the matching 2^d-times larger tiles of
+// the finer levels; it loads the level-0 region those tiles depend on into LDS and runs the pyrDown
+// chain there (halo recompute instead of a kernel boundary per level: a dependent launch costs
+// ~5 us here, the recompute ~1.7x of the arithmetic).  Region at level k-1 = 2*region(k) + 3.
+// Out-of-image coordinates are never materialised: taps go through REFLECT_101 on the source level.
+// The REFLECT_101 border bands of the planes are filled by pyramid_borders afterwards.
+constexpr int FUSE_MAX_LEVELS = 5;
+struct FusePlan {
+    int levels, tw, th, halo;
+    int n[FUSE_MAX_LEVELS], m[FUSE_MAX_LEVELS], off[FUSE_MAX_LEVELS];
+};
+__device__ __forceinline__ int refl1(int c, int n) {      // one reflection is enough here (|overshoot| <= 2)
+    if (n == 1) return 0;
+    return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c);
+}
+
+__global__ __launch_bounds__(1024) void pyramid_fused(const uint8_t* __restrict__ src, int spitch, size_t img_stride,
+                                                     const VofeLevel* __restrict__ lv, FusePlan P, int slot0,
+                                                     int with_deriv) {
+    extern __shared__ uint8_t R[];
+    const int T = P.levels - 1;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = (int)blockDim.x >> 5;
+    int lox[FUSE_MAX_LEVELS], loy[FUSE_MAX_LEVELS];
+    lox[T] = (int)blockIdx.x * P.tw - P.halo;
+    loy[T] = (int)blockIdx.y * P.th - P.halo;
+#pragma unroll
+    for (int k = FUSE_MAX_LEVELS - 1; k >= 1; --k)
+        if (k <= T) { lox[k - 1] = 2 * lox[k] - 2; loy[k - 1] = 2 * loy[k] - 2; }
+    const int slot = slot0 + (int)blockIdx.z;
+    {   // level-0 region from the caller's image
+        const VofeLevel L = lv[0];
+        const uint8_t* im = src + (size_t)blockIdx.z * img_stride;
+        uint8_t* r0 = R + P.off[0];
+        for (int j = ty; j < P.m[0]; j += nty) {
+            const int cy = loy[0] + j;
+            if (cy < 0 || cy >= L.h) continue;
+            const uint8_t* row = im + (size_t)cy * spitch;
+            for (int i = tx; i < P.n[0]; i += 32) {
+                const int cx = lox[0] + i;
+                if (cx >= 0 && cx < L.w) r0[j * P.n[0] + i] = row[cx];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < FUSE_MAX_LEVELS; ++k) {
+        if (k > T) break;
+        const int wk = lv[k].w, hk = lv[k].h, wp = lv[k - 1].w, hp = lv[k - 1].h;
+        const uint8_t* rp = R + P.off[k - 1];
+        uint8_t* rk = R + P.off[k];
+        const int np = P.n[k - 1];
+        for (int j = ty; j < P.m[k]; j += nty) {
+            const int Y = loy[k] + j;
+            if (Y < 0 || Y >= hk) continue;
+            int ry[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) ry[r] = (refl1(2 * Y - 2 + r, hp) - loy[k - 1]) * np;
+            for (int i = tx; i < P.n[k]; i += 32) {
+                const int X = lox[k] + i;
+                if (X < 0 || X >= wk) continue;
+                int rx[5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) rx[c] = refl1(2 * X - 2 + c, wp) - lox[k - 1];
+                int acc = 128;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const uint8_t* row = rp + ry[r];
+                    const int hs = (int)row[rx[0]] + (int)row[rx[4]] + 4 * ((int)row[rx[1]] + (int)row[rx[3]]) + 6 * (int)row[rx[2]];
+                    acc += ((r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4)) * hs;
+                }
+                rk[j * P.n[k] + i] = (uint8_t)(acc >> 8);
+            }
+        }
+        __syncthreads();
+    }
+    // owned tiles of every level -> global planes (+ Scharr)
+#pragma unroll
+    for (int k = 0; k < FUSE_MAX_LEVELS; ++k) {
+        if (k > T) break;
+        const VofeLevel L = lv[k];
+        const int d = T - k;
+        const int ox0 = ((int)blockIdx.x * P.tw) << d, oy0 = ((int)blockIdx.y * P.th) << d;
+        const int ox1 = min(ox0 + (P.tw << d), L.w), oy1 = min(oy0 + (P.th << d), L.h);
+        if (ox0 >= ox1 || oy0 >= oy1) continue;
+        const uint8_t* rk = R + P.off[k];
+        const int nk = P.n[k];
+        const long long so = (long long)slot * L.slot_stride;
+        for (int y = oy0 + ty; y < oy1; y += nty) {
+            const uint8_t* row = rk + (y - loy[k]) * nk - lox[k];
+            uint8_t* drow = L.I + so + (long long)y * L.pitch;
+            for (int x = ox0 + tx * 4; x < ox1; x += 128) {
+                if (x + 4 <= ox1) {
+                    const unsigned v = (unsigned)row[x] | ((unsigned)row[x + 1] << 8) | ((unsigned)row[x + 2] << 16) | ((unsigned)row[x + 3] << 24);
+                    *reinterpret_cast<unsigned*>(drow + x) = v;
+                } else {
+                    for (int q = x; q < ox1; ++q) drow[q] = row[q];
+                }
+            }
+            if (with_deriv) {
+                const uint8_t* ra = rk + (refl1(y - 1, L.h) - loy[k]) * nk - lox[k];
+                const uint8_t* rc = rk + (refl1(y + 1, L.h) - loy[k]) * nk - lox[k];
+                int* dd = L.D + so + (long long)y * L.pitch;
+                for (int x = ox0 + tx; x < ox1; x += 32) {
+                    const int xm = refl1(x - 1, L.w), xp = refl1(x + 1, L.w);
+                    const int a0 = ra[xm], a1 = ra[x], a2 = ra[xp];
+                    const int b0 = row[xm], b2 = row[xp];
+                    const int c0 = rc[xm], c1 = rc[x], c2 = rc[xp];
+                    const int ix = (3 * (a2 + c2) + 10 * b2) - (3 * (a0 + c0) + 10 * b0);
+                    const int iy = 3 * ((c0 - a0) + (c2 - a2)) + 10 * (c1 - a1);
+                    dd[x] = (int)(((unsigned)ix & 0xffffu) | ((unsigned)iy << 16));
+                }
+            }
+        }
+    }
+}
+
+// REFLECT_101 border bands of every level in one launch (reads the interiors written by
+// pyramid_fused).  One thread = 16 bytes of one padded row; fully interior groups return at once.
+__global__ __launch_bounds__(256) void pyramid_borders(const VofeLevel* __restrict__ lv, ScharrPlan plan, int slot0,
+                                                       int win_w, int win_h) {
+    int level = 0;
+    while (level + 1 < plan.levels && (int)blockIdx.x >= plan.blk_start[level + 1]) ++level;
+    const VofeLevel L = lv[level];
+    const int b = (int)blockIdx.x - plan.blk_start[level];
+    const int bx = b % plan.blk_x[level], by = b / plan.blk_x[level];
+    const int gx0 = -((win_w + 15) / 16);
+    const int g = bx * 64 + (threadIdx.x & 63) + gx0;
+    const int y = by * 4 + (threadIdx.x >> 6) - win_h;
+    const int x0 = g * 16;
+    if (y >= L.h + win_h || x0 >= L.w + win_w) return;
+    if (y >= 0 && y < L.h && x0 >= 0 && x0 + 16 <= L.w) return;
+    uint8_t* base = L.I + (long long)(slot0 + (int)blockIdx.y) * L.slot_stride;
+    const uint8_t* srow = base + (long long)vofe_reflect101(y, L.h) * L.pitch;
+    uint8_t bytes[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bytes[i] = srow[vofe_reflect101(x0 + i, L.w)];
+    uint4 v;
+    __builtin_memcpy(&v, bytes, 16);
+    *reinterpret_cast<uint4*>(base + (long long)y * L.pitch + x0) = v;
+}
+
 inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }   // floor division
 
 }  // namespace
@@ -160,6 +306,38 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
                         int pitch, size_t img_stride) {
     hipStream_t st = ctx->stream;
     const int ww = pyr->win_w, wh = pyr->win_h;
+    if (pyr->levels <= FUSE_MAX_LEVELS && !getenv("VOFE_PYRAMID_UNFUSED")) {
+        // fused path: 2 launches (interiors + Scharr, then border bands)
+        FusePlan P;
+        P.levels = pyr->levels;
+        const int T = P.levels - 1;
+        P.tw = P.th = (T == 0) ? 64 : (T == 1 ? 32 : (T == 2 ? 16 : 8));
+        P.halo = pyr->with_deriv ? 1 : 0;
+        P.n[T] = P.tw + 2 * P.halo; P.m[T] = P.th + 2 * P.halo;
+        for (int k = T; k >= 1; --k) { P.n[k - 1] = 2 * P.n[k] + 3; P.m[k - 1] = 2 * P.m[k] + 3; }
+        int off = 0;
+        for (int k = 0; k <= T; ++k) { P.off[k] = off; off += (P.n[k] * P.m[k] + 15) / 16 * 16; }
+        for (int k = T + 1; k < FUSE_MAX_LEVELS; ++k) { P.n[k] = P.m[k] = P.off[k] = 0; }
+        const VofeLevel& Lt = pyr->lv[T];
+        dim3 grid((Lt.w + P.tw - 1) / P.tw, (Lt.h + P.th - 1) / P.th, count);
+        if (grid.y > 65535) { vofe_set_error("pyramid: image too tall"); return VOFE_E_UNSUPPORTED; }
+        hipLaunchKernelGGL(pyramid_fused, grid, dim3(1024), (size_t)off, st, d_img, pitch, img_stride, pyr->d_lv, P, slot0,
+                           pyr->with_deriv);
+        ScharrPlan plan;
+        plan.levels = pyr->levels;
+        int total = 0;
+        for (int l = 0; l < pyr->levels; ++l) {
+            const int groups = (ww + 15) / 16 + (pyr->lv[l].w + ww + 15) / 16;
+            plan.blk_start[l] = total;
+            plan.blk_x[l] = (groups + 63) / 64;
+            total += plan.blk_x[l] * ((pyr->lv[l].h + 2 * wh + 3) / 4);
+        }
+        plan.blk_start[pyr->levels] = total;
+        hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");
+        return VOFE_OK;
+    }
     {
         const VofeLevel& L = pyr->lv[0];
         const int gx0 = fdiv(-ww, 16), gx1 = fdiv(L.w + ww - 1, 16);
