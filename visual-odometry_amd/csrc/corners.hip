@@ -119,18 +119,26 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 
 // ---------------------------------------------------------------------------------------------
 // threshold + 3x3 local maximum + compaction.  state: 0 none, 1 undecided.
+constexpr int NMS_ROWS = 8;      // rows per thread: a 256-thread block covers 64 x 32 pixels
 __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ score, int h, int w, double quality,
                                                    GfttHdr* __restrict__ hdr, uint8_t* __restrict__ state,
                                                    unsigned* __restrict__ cand, const uint8_t* __restrict__ mask) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = blockIdx.y * (4 * NMS_ROWS) + wv;
     const size_t ib = (size_t)blockIdx.z * h * w;
     const float* sc = score + ib;
     const unsigned mk = hdr[blockIdx.z].max_key;
-    bool is = false;
-    if (x < w && y < h && mk) {
-        const float thr = (float)((double)key_float(mk) * quality);
-        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+    const float thr = mk ? (float)((double)key_float(mk) * quality) : 0.f;
+    unsigned long long bal[NMS_ROWS];
+    unsigned total = 0;
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS; ++k) {
+        const int y = y0 + 4 * k;
+        bool is = false;
+        if (mk && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
             const float* p = sc + (size_t)y * w + x;
             const float v = p[0];
             if (v > thr && v != 0.f && (!mask || mask[(size_t)y * w + x])) {
@@ -140,16 +148,24 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
                 is = v >= m;
             }
         }
+        if (x < w && y < h) state[ib + (size_t)y * w + x] = is ? 1 : 0;
+        bal[k] = __ballot(is);
+        total += (unsigned)__popcll(bal[k]);
     }
-    if (x < w && y < h) state[ib + (size_t)y * w + x] = is ? 1 : 0;
-    const unsigned long long bal = __ballot(is);
-    if (bal) {
-        const int lane = threadIdx.x & 63;
-        unsigned base = 0;
-        const int leader = __ffsll((long long)bal) - 1;
-        if (lane == leader) base = atomicAdd(&hdr[blockIdx.z].n_cand, (unsigned)__popcll(bal));
-        base = (unsigned)__shfl((int)base, leader);
-        if (is) cand[ib + base + __popcll(bal & ((1ull << lane) - 1))] = (unsigned)(y * w + x);
+    if (lane == 0) s_wave[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = t ? atomicAdd(&hdr[blockIdx.z].n_cand, t) : 0u;
+    }
+    __syncthreads();
+    unsigned pos = s_base;
+    for (int q = 0; q < wv; ++q) pos += s_wave[q];
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS; ++k) {
+        if ((bal[k] >> lane) & 1ull)
+            cand[ib + pos + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned)((y0 + 4 * k) * w + x);
+        pos += (unsigned)__popcll(bal[k]);
     }
 }
 
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(256) void select_round(const float* __restrict__ sc
         if (lane == 0) {
             if (any_rej) stt[p] = 3;
             else if (!any_blk) stt[p] = 2;
-            else atomicAdd(&hdr[blockIdx.y].undecided[round], 1u);
+            else hdr[blockIdx.y].undecided[round] = 1u;      // flag only: a counter here is one contended atomic per wave
         }
     }
 }
@@ -229,28 +245,30 @@ __device__ __forceinline__ void cmpx(unsigned long long* s, unsigned i, unsigned
     if (a < b) { s[i] = b; s[p] = a; }
 }
 
-// mode 0: full sort of each SORT_CH chunk; mode 1: steps j = SORT_CH/2 .. 1 of a larger stage.
+// mode 0: full sort of each chunk of `len` keys (power of two <= SORT_CH; SORT_CH unless there is a
+// single chunk); mode 1: steps j = SORT_CH/2 .. 1 of a larger stage.
 // emit != 0 (single chunk only): write the first min(n, max_out) corners as (x,y) floats.
 __global__ __launch_bounds__(SORT_THREADS) void sort_local(unsigned long long* __restrict__ keys, const GfttHdr* __restrict__ hdr,
                                                            size_t key_stride, int mode, int emit, int w,
-                                                           float* __restrict__ corners, int out_stride, int max_out) {
+                                                           float* __restrict__ corners, int out_stride, int max_out,
+                                                           unsigned len) {
     extern __shared__ unsigned long long sk[];
     const unsigned n = hdr[blockIdx.y].n_acc;
     const unsigned base = blockIdx.x * SORT_CH;
     if (base >= n) return;
     unsigned long long* g = keys + (size_t)blockIdx.y * key_stride;
-    for (unsigned e = threadIdx.x; e < SORT_CH; e += SORT_THREADS) sk[e] = (base + e < n) ? g[base + e] : 0ull;
+    for (unsigned e = threadIdx.x; e < len; e += SORT_THREADS) sk[e] = (base + e < n) ? g[base + e] : 0ull;
     __syncthreads();
     if (mode == 0) {
-        for (unsigned k = 2; k <= SORT_CH; k <<= 1) {
-            for (unsigned t = threadIdx.x; t < SORT_CH / 2; t += SORT_THREADS) {       // mirror step
+        for (unsigned k = 2; k <= len; k <<= 1) {
+            for (unsigned t = threadIdx.x; t < len / 2; t += SORT_THREADS) {       // mirror step
                 const unsigned blk = t / (k / 2), o = t - blk * (k / 2);
                 const unsigned i = blk * k + o, p = blk * k + (k - 1 - o);
                 cmpx(sk, i, p);
             }
             __syncthreads();
             for (unsigned j = k >> 2; j > 0; j >>= 1) {
-                for (unsigned t = threadIdx.x; t < SORT_CH / 2; t += SORT_THREADS) {
+                for (unsigned t = threadIdx.x; t < len / 2; t += SORT_THREADS) {
                     const unsigned i = ((t / j) * 2 * j) + (t % j);
                     cmpx(sk, i, i + j);
                 }
@@ -258,15 +276,15 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_local(unsigned long long* _
             }
         }
     } else {
-        for (unsigned j = SORT_CH >> 1; j > 0; j >>= 1) {
-            for (unsigned t = threadIdx.x; t < SORT_CH / 2; t += SORT_THREADS) {
+        for (unsigned j = len >> 1; j > 0; j >>= 1) {
+            for (unsigned t = threadIdx.x; t < len / 2; t += SORT_THREADS) {
                 const unsigned i = ((t / j) * 2 * j) + (t % j);
                 cmpx(sk, i, i + j);
             }
             __syncthreads();
         }
     }
-    for (unsigned e = threadIdx.x; e < SORT_CH; e += SORT_THREADS)
+    for (unsigned e = threadIdx.x; e < len; e += SORT_THREADS)
         if (base + e < n) g[base + e] = sk[e];
     if (emit) {
         const unsigned m = min(n, (unsigned)max_out);
@@ -366,7 +384,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_compact, dim3((w + 63) / 64, (h + 3) / 4, batch), dim3(256), 0, st, score, h, w, quality, hdr,
+    hipLaunchKernelGGL(nms_compact, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st, score, h, w, quality, hdr,
                        state, cand, d_mask);
     const bool suppress = min_distance >= 1.0;
     int r = 0;
@@ -416,11 +434,13 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const unsigned chunks = (nmax + SORT_CH - 1) / SORT_CH;
     const size_t lds = (size_t)SORT_CH * 8;
     if (chunks == 1) {
-        hipLaunchKernelGGL(sort_local, dim3(1, batch), dim3(SORT_THREADS), lds, st, keys, hdr, px, 0, 1, w, d_corners_xy,
-                           capacity, max_out);
+        unsigned len = 64;
+        while (len < nmax) len <<= 1;
+        hipLaunchKernelGGL(sort_local, dim3(1, batch), dim3(SORT_THREADS), (size_t)len * 8, st, keys, hdr, px, 0, 1, w,
+                           d_corners_xy, capacity, max_out, len);
     } else {
         hipLaunchKernelGGL(sort_local, dim3(chunks, batch), dim3(SORT_THREADS), lds, st, keys, hdr, px, 0, 0, w,
-                           d_corners_xy, capacity, max_out);
+                           d_corners_xy, capacity, max_out, (unsigned)SORT_CH);
         unsigned npow = SORT_CH;
         while (npow < nmax) npow <<= 1;
         const unsigned pair_blocks = (npow / 2 + 255) / 256;
@@ -429,7 +449,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             for (unsigned j = kk >> 2; j >= (unsigned)SORT_CH; j >>= 1)
                 hipLaunchKernelGGL(sort_global_step, dim3(pair_blocks, batch), dim3(256), 0, st, keys, hdr, px, kk, j, 0);
             hipLaunchKernelGGL(sort_local, dim3(chunks, batch), dim3(SORT_THREADS), lds, st, keys, hdr, px, 1, 0, w,
-                               d_corners_xy, capacity, max_out);
+                               d_corners_xy, capacity, max_out, (unsigned)SORT_CH);
         }
         if (max_out > 0)
             hipLaunchKernelGGL(emit_corners, dim3((max_out + 255) / 256, batch), dim3(256), 0, st, keys, hdr, px, w,
