@@ -247,6 +247,41 @@ def test_gftt_large_sort(fe):
     assert ref.shape[0] == 20000 and np.array_equal(got, ref)
 
 
+def test_gftt_bitonic_network_forced(fe, monkeypatch):
+    """The rank sort serves up to 32768 corners; the bitonic network behind it must stay exact too."""
+    monkeypatch.setenv("VOFE_GFTT_SORT", "bitonic")
+    a = _seq(700, 900, 31, 1)[0]
+    for args in ((0, 0.0005, 1), (20000, 0.0005, 0), (500, 0.01, 6)):
+        assert np.array_equal(fe.goodFeaturesToTrack(a, *args), oracle.goodFeaturesToTrack(a, *args, nthreads=8))
+
+
+def test_gftt_rank_prefix_growth_and_large_windows(fe):
+    """maxCorners just below / above what the image holds (the selection widens its rank prefix until
+    enough corners are accepted or the list ends), and minDistance beyond the register-window limit."""
+    a = _seq(600, 800, 1, 1)[0]
+    full = oracle.goodFeaturesToTrack(a, 0, 0.01, 10, nthreads=8).shape[0]
+    for maxc in (full - 1, full, full + 1, full // 2, 3 * full, 7):
+        assert np.array_equal(fe.goodFeaturesToTrack(a, maxc, 0.01, 10), oracle.goodFeaturesToTrack(a, maxc, 0.01, 10, nthreads=8))
+    for md in (9.99, 10.5, 15, 33.3, 70):
+        for maxc in (0, 40):
+            assert np.array_equal(fe.goodFeaturesToTrack(a, maxc, 0.01, md), oracle.goodFeaturesToTrack(a, maxc, 0.01, md, nthreads=8))
+
+
+def test_gftt_batch_mixed_prefix_needs(fe):
+    """One image of the batch runs out of corners while the others have plenty."""
+    import torch
+    imgs = np.stack([_seq(240, 320, 50 + i, 1)[0] for i in range(3)])
+    imgs[1, :, :] = 10
+    imgs[1, 100:140, 100:160] = _seq(40, 60, 77, 1)[0]
+    out, cnt = fe.goodFeaturesToTrack_batch(torch.from_numpy(imgs).cuda(), 150, 0.01, 6)
+    out = out.cpu().numpy()
+    for i in range(3):
+        ref = oracle.goodFeaturesToTrack(imgs[i], 150, 0.01, 6)
+        assert cnt[i] == ref.shape[0]
+        assert np.array_equal(out[i, :cnt[i]], ref.reshape(-1, 2))
+    assert cnt[1] < 150 <= cnt[0]
+
+
 def test_gftt_batch(fe):
     import torch
     imgs = np.stack([_seq(200, 300, 40 + i, 1)[0] for i in range(5)])

@@ -25,13 +25,35 @@ constexpr int SORT_CH = 8192;                   // keys sorted in LDS per block 
 constexpr int SORT_THREADS = 1024;
 constexpr int SELECT_ROUNDS = 8;                // rounds launched between host checks
 
+constexpr int N_SEG = 8;                        // growing rank prefixes tried by the selection
+constexpr int BUCKET_BITS = 13;
+constexpr int N_BUCKET = 1 << BUCKET_BITS;      // score buckets of the coarse rank order (fine: few atomics collide)
+
 struct GfttHdr {
     unsigned max_key;       // order-preserving key of the global score maximum (0 = none)
     unsigned n_cand;
     unsigned n_acc;
     unsigned pad;
     unsigned undecided[SELECT_ROUNDS];
+    unsigned seg_end[N_SEG];    // prefix lengths of the bucket-ordered candidate list (bucket boundaries)
 };
+
+// Coarse rank order: bucket 0 holds the highest scores.  Buckets partition the positive-float bit
+// range (threshold, max] monotonically, so every candidate of a lower bucket outranks every
+// candidate of a higher one; the order inside a bucket is arbitrary (ranks are always compared
+// exactly on (score bits, index), the list order only steers the schedule and the prefix cut).
+struct BucketMap { unsigned mb, shift; };
+__device__ __forceinline__ BucketMap bucket_map(unsigned max_key, float thr) {
+    BucketMap m;
+    m.mb = max_key & 0x7fffffffu;                               // bits of the (positive) maximum
+    const unsigned tb = __float_as_uint(thr);
+    const unsigned range = m.mb > tb ? m.mb - tb : 0u;
+    const int bits = 32 - __clz((int)range | 1);
+    m.shift = bits > BUCKET_BITS ? (unsigned)(bits - BUCKET_BITS) : 0u;
+    return m;
+}
+__device__ __forceinline__ unsigned bucket_of(const BucketMap& m, unsigned kb) { return (m.mb - kb) >> m.shift; }
+__device__ __forceinline__ float gftt_threshold(unsigned mk, double quality);
 
 __device__ __forceinline__ unsigned float_key(float v) {
     const unsigned b = __float_as_uint(v);
@@ -39,6 +61,10 @@ __device__ __forceinline__ unsigned float_key(float v) {
 }
 __device__ __forceinline__ float key_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ __forceinline__ float gftt_threshold(unsigned mk, double quality) {
+    return mk ? (float)((double)key_float(mk) * quality) : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -118,11 +144,14 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// threshold + 3x3 local maximum + compaction.  state: 0 none, 1 undecided.
+// threshold + 3x3 local maximum + compaction.
+// state map (u16 per pixel): 0 = no candidate, else (score bucket << 2) | state, state 1 = undecided.
 constexpr int NMS_ROWS = 8;      // rows per thread: a 256-thread block covers 64 x 32 pixels
 __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ score, int h, int w, double quality,
-                                                   GfttHdr* __restrict__ hdr, uint8_t* __restrict__ state,
-                                                   unsigned* __restrict__ cand, const uint8_t* __restrict__ mask) {
+                                                   GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
+                                                   unsigned* __restrict__ ckey, unsigned* __restrict__ cand,
+                                                   size_t cand_stride, unsigned* __restrict__ hist,
+                                                   const uint8_t* __restrict__ mask) {
     __shared__ unsigned s_wave[4];
     __shared__ unsigned s_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -131,16 +160,19 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
     const size_t ib = (size_t)blockIdx.z * h * w;
     const float* sc = score + ib;
     const unsigned mk = hdr[blockIdx.z].max_key;
-    const float thr = mk ? (float)((double)key_float(mk) * quality) : 0.f;
+    const float thr = gftt_threshold(mk, quality);
+    const BucketMap bm = bucket_map(mk, thr);
+    unsigned* hs = hist + (size_t)blockIdx.z * N_BUCKET;
     unsigned long long bal[NMS_ROWS];
     unsigned total = 0;
 #pragma unroll
     for (int k = 0; k < NMS_ROWS; ++k) {
         const int y = y0 + 4 * k;
         bool is = false;
+        float v = 0.f;
         if (mk && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
             const float* p = sc + (size_t)y * w + x;
-            const float v = p[0];
+            v = p[0];
             if (v > thr && v != 0.f && (!mask || mask[(size_t)y * w + x])) {
                 float m = fmaxf(fmaxf(p[-w - 1], p[-w]), p[-w + 1]);
                 m = fmaxf(m, fmaxf(p[-1], p[1]));
@@ -148,7 +180,12 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
                 is = v >= m;
             }
         }
-        if (x < w && y < h) state[ib + (size_t)y * w + x] = is ? 1 : 0;
+        if (x < w && y < h) {
+            const unsigned d = is ? bucket_of(bm, __float_as_uint(v)) : 0u;
+            state[ib + (size_t)y * w + x] = is ? (uint16_t)((d << 2) | 1u) : (uint16_t)0;
+            ckey[ib + (size_t)y * w + x] = is ? __float_as_uint(v) : 0u;
+            if (is) atomicAdd(&hs[d], 1u);
+        }
         bal[k] = __ballot(is);
         total += (unsigned)__popcll(bal[k]);
     }
@@ -164,74 +201,249 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
 #pragma unroll
     for (int k = 0; k < NMS_ROWS; ++k) {
         if ((bal[k] >> lane) & 1ull)
-            cand[ib + pos + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned)((y0 + 4 * k) * w + x);
+            cand[(size_t)blockIdx.z * cand_stride + pos + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned)((y0 + 4 * k) * w + x);
         pos += (unsigned)__popcll(bal[k]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// one round of the min-distance fixed point: one wavefront per candidate, grid-stride.
-// state: 1 undecided, 2 accepted, 3 rejected.  Any interleaving of rounds gives the same fixed
-// point because a decision is only taken from final (2/3) states of higher-ranked neighbours.
-__global__ __launch_bounds__(256) void select_round(const float* __restrict__ score, int h, int w, int r, float md2,
-                                                    GfttHdr* __restrict__ hdr, uint8_t* __restrict__ state,
-                                                    const unsigned* __restrict__ cand, int round) {
-    const size_t ib = (size_t)blockIdx.y * h * w;
-    const float* sc = score + ib;
-    uint8_t* stt = state + ib;
-    const unsigned n = hdr[blockIdx.y].n_cand;
-    const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    const int side = 2 * r + 1, area = side * side;
-    for (unsigned c = wave; c < n; c += nwaves) {
-        const unsigned p = cand[ib + c];
-        if (stt[p] != 1) continue;
-        const int py = (int)(p / (unsigned)w), px = (int)(p - (unsigned)py * w);
-        const unsigned pbits = __float_as_uint(sc[p]);
-        bool rej = false, blocked = false;
-        for (int e = lane; e < area; e += 64) {
-            const int dy = e / side - r, dx = e - (dy + r) * side - r;
-            const int qx = px + dx, qy = py + dy;
-            if (qx < 0 || qx >= w || qy < 0 || qy >= h) continue;
-            if ((float)(dx * dx + dy * dy) >= md2) continue;
-            const unsigned q = (unsigned)(qy * w + qx);
-            const unsigned s = stt[q];
-            if (s == 0 || s == 3 || q == p) continue;
-            const unsigned qbits = __float_as_uint(sc[q]);
-            const bool higher = qbits > pbits || (qbits == pbits && q > p);   // scores are > 0: bit order = value order
-            if (!higher) continue;
-            if (s == 2) rej = true; else blocked = true;
-        }
-        const bool any_rej = __any(rej), any_blk = __any(blocked);
-        if (lane == 0) {
-            if (any_rej) stt[p] = 3;
-            else if (!any_blk) stt[p] = 2;
-            else hdr[blockIdx.y].undecided[round] = 1u;      // flag only: a counter here is one contended atomic per wave
-        }
+// exclusive scan of the bucket histogram (one 1024-thread block per image, 4 buckets per thread)
+// -> scatter cursors, and the prefix lengths seg_end[k] = first bucket boundary >= min(n, base<<k)
+// (base = 0: everything).
+__global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
+                                                    GfttHdr* __restrict__ hdr, unsigned base) {
+    __shared__ unsigned s_w[16];
+    const unsigned* hs = hist + (size_t)blockIdx.x * N_BUCKET;
+    unsigned* cs = cursor + (size_t)blockIdx.x * N_BUCKET;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int BPT = N_BUCKET / 1024;                 // consecutive buckets per thread
+    unsigned cnt[BPT], ex[BPT];
+    unsigned mine = 0;
+#pragma unroll
+    for (int i = 0; i < BPT / 4; ++i) {
+        const uint4 v = reinterpret_cast<const uint4*>(hs)[t * (BPT / 4) + i];
+        cnt[4 * i] = v.x; cnt[4 * i + 1] = v.y; cnt[4 * i + 2] = v.z; cnt[4 * i + 3] = v.w;
+        mine += v.x + v.y + v.z + v.w;
+    }
+    unsigned inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    unsigned off = 0;
+    for (int q = 0; q < wv; ++q) off += s_w[q];
+    const unsigned n = hdr[blockIdx.x].n_cand;
+    unsigned e0 = off + inc - mine;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { ex[i] = e0; e0 += cnt[i]; }
+#pragma unroll
+    for (int i = 0; i < BPT / 4; ++i)
+        reinterpret_cast<uint4*>(cs)[t * (BPT / 4) + i] = make_uint4(ex[4 * i], ex[4 * i + 1], ex[4 * i + 2], ex[4 * i + 3]);
+    if (mine == 0 && t != 0) return;
+    for (int k = 0; k < N_SEG; ++k) {
+        unsigned long long want = base ? ((unsigned long long)base << k) : (unsigned long long)n;
+        if (k == N_SEG - 1 || want > n) want = n;
+        const unsigned tk = (unsigned)want;
+        if (tk == 0) { if (t == 0) hdr[blockIdx.x].seg_end[k] = 0; continue; }
+        if (!(ex[0] < tk && e0 >= tk)) continue;          // the boundary bucket is not among this thread's
+#pragma unroll
+        for (int i = 0; i < BPT; ++i)
+            if (cnt[i] && ex[i] < tk && ex[i] + cnt[i] >= tk) hdr[blockIdx.x].seg_end[k] = ex[i] + cnt[i];
     }
 }
 
-// gather accepted candidates as 64-bit keys (score bits << 32 | linear index)
-__global__ __launch_bounds__(256) void gather_accepted(const float* __restrict__ score, int h, int w,
-                                                       GfttHdr* __restrict__ hdr, const uint8_t* __restrict__ state,
-                                                       const unsigned* __restrict__ cand, unsigned long long* __restrict__ keys,
-                                                       int take_all) {
-    const size_t ib = (size_t)blockIdx.y * h * w;
+// bucket-ordered candidate list
+__global__ __launch_bounds__(256) void bucket_scatter(const unsigned* __restrict__ ckey, size_t px, double quality,
+                                                      const GfttHdr* __restrict__ hdr, const unsigned* __restrict__ cand,
+                                                      size_t cand_stride, unsigned* __restrict__ cursor,
+                                                      unsigned* __restrict__ sorted) {
     const unsigned n = hdr[blockIdx.y].n_cand;
+    const unsigned mk = hdr[blockIdx.y].max_key;
+    const BucketMap bm = bucket_map(mk, gftt_threshold(mk, quality));
+    for (unsigned c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+        const unsigned p = cand[(size_t)blockIdx.y * cand_stride + c];
+        const unsigned d = bucket_of(bm, ckey[(size_t)blockIdx.y * px + p]);
+        const unsigned pos = atomicAdd(&cursor[(size_t)blockIdx.y * N_BUCKET + d], 1u);
+        sorted[(size_t)blockIdx.y * px + pos] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// min-distance fixed point: one wavefront per candidate, grid-stride over the bucket-ordered list.
+// State map entry: (bucket << 2) | state, state 1 undecided, 2 accepted, 3 rejected, 0 = no
+// candidate.  The bucket is a coarse rank, so one 2-byte load per window pixel tells whether a
+// neighbour exists, whether it outranks the centre (exact (score bits, index) comparison through
+// ckey only when the buckets tie) and what its state is.  Any schedule gives the same fixed point
+// because a decision is only taken from final (2/3) states of higher-ranked neighbours.  One launch
+// makes `passes` sweeps over its candidates and re-reads the blocking neighbours up to `spins`
+// times per visit; state traffic goes through L2 (agent-scope relaxed atomics = sc1 loads/stores)
+// so sweeps see other waves' decisions.
+__device__ __forceinline__ unsigned ld_state(const uint16_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(uint16_t* p, unsigned v) {
+    __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int SEL_CH = 6;        // window entries per lane held in registers (windows up to 19x19)
+
+__device__ __forceinline__ bool outranks(const unsigned* __restrict__ ck, unsigned vq, unsigned q, unsigned dp, unsigned p) {
+    const unsigned dq = vq >> 2;
+    if (dq != dp) return dq < dp;
+    const unsigned kq = ck[q], kp = ck[p];
+    return kq > kp || (kq == kp && q > p);
+}
+
+struct SelGeom { int h, w, r, side, area; float md2, inv_side; };
+struct SelWin { unsigned p, myv, q[SEL_CH], v[SEL_CH]; };
+
+// issue the loads of one candidate's window (register-resident windows only)
+__device__ __forceinline__ void sel_fetch(const SelGeom& g, const uint16_t* stt, unsigned p, int lane, SelWin& W) {
+    W.p = p;
+    W.myv = ld_state(stt + p);
+    const int py = (int)(p / (unsigned)g.w), px = (int)(p - (unsigned)py * g.w);
+#pragma unroll
+    for (int i = 0; i < SEL_CH; ++i) {
+        const int e = lane + 64 * i;
+        const int ey = (int)(((float)e + 0.5f) * g.inv_side);                 // e / side, exact for e < 4096
+        const int dy = ey - g.r, dx = e - ey * g.side - g.r;
+        const int qx = px + dx, qy = py + dy;
+        const bool ok = e < g.area && qx >= 0 && qx < g.w && qy >= 0 && qy < g.h && (float)(dx * dx + dy * dy) < g.md2;
+        W.q[i] = ok ? (unsigned)(qy * g.w + qx) : p;
+        W.v[i] = ld_state(stt + W.q[i]);
+    }
+}
+
+// decide one candidate from its (possibly slightly old) window; blocking neighbours are re-read.
+// Returns true when the candidate is still undecided.
+__device__ __forceinline__ bool sel_eval(const unsigned* __restrict__ ck, uint16_t* stt, const SelWin& W, int lane, int spins) {
+    if ((W.myv & 3u) != 1u) return false;
+    const unsigned dp = W.myv >> 2, p = W.p;
+    bool rel[SEL_CH];
+    bool rej = false, blk = false;
+#pragma unroll
+    for (int i = 0; i < SEL_CH; ++i) {
+        const unsigned st = W.v[i] & 3u;
+        rel[i] = false;
+        if (W.q[i] == p || st == 0u || st == 3u) continue;
+        if (!outranks(ck, W.v[i], W.q[i], dp, p)) continue;
+        if (st == 2u) rej = true; else { blk = true; rel[i] = true; }
+    }
+    bool any_rej = __any(rej), any_blk = __any(blk);
+    for (int spin = 0; !any_rej && any_blk && spin < spins; ++spin) {
+        if (spin) __builtin_amdgcn_s_sleep(8);
+        rej = false; blk = false;
+#pragma unroll
+        for (int i = 0; i < SEL_CH; ++i) {
+            if (!rel[i]) continue;
+            const unsigned st = ld_state(stt + W.q[i]) & 3u;
+            if (st == 2u) rej = true; else if (st == 1u) blk = true; else rel[i] = false;
+        }
+        any_rej = __any(rej); any_blk = __any(blk);
+    }
+    if (any_rej) { if (lane == 0) st_state(stt + p, (dp << 2) | 3u); return false; }
+    if (!any_blk) { if (lane == 0) st_state(stt + p, (dp << 2) | 2u); return false; }
+    return true;
+}
+
+// windows too large for registers: plain scan
+__device__ __forceinline__ bool sel_visit_large(const SelGeom& g, const unsigned* __restrict__ ck, uint16_t* stt, unsigned p, int lane) {
+    const unsigned myv = ld_state(stt + p);
+    if ((myv & 3u) != 1u) return false;
+    const unsigned dp = myv >> 2;
+    const int py = (int)(p / (unsigned)g.w), px = (int)(p - (unsigned)py * g.w);
+    bool rej = false, blk = false;
+    for (int e = lane; e < g.area; e += 64) {
+        const int dy = e / g.side - g.r, dx = e - (dy + g.r) * g.side - g.r;
+        const int qx = px + dx, qy = py + dy;
+        if (qx < 0 || qx >= g.w || qy < 0 || qy >= g.h) continue;
+        if ((float)(dx * dx + dy * dy) >= g.md2) continue;
+        const unsigned q = (unsigned)(qy * g.w + qx);
+        const unsigned vq = ld_state(stt + q), st = vq & 3u;
+        if (q == p || st == 0u || st == 3u || !outranks(ck, vq, q, dp, p)) continue;
+        if (st == 2u) rej = true; else blk = true;
+    }
+    if (__any(rej)) { if (lane == 0) st_state(stt + p, (dp << 2) | 3u); return false; }
+    if (!__any(blk)) { if (lane == 0) st_state(stt + p, (dp << 2) | 2u); return false; }
+    return true;
+}
+
+// A wave owns candidates wave, wave + nwaves, ... of the bucket-ordered list, in chunks of 64: a first
+// sweep with the next candidate's window loads in flight while the current one is decided, then up
+// to passes-1 sweeps over the ones still blocked (bit mask).
+__global__ __launch_bounds__(256) void select_round(const unsigned* __restrict__ ckey, int h, int w, int r, float md2,
+                                                    GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
+                                                    const unsigned* __restrict__ cand, int seg, int passes, int spins, int slot) {
+    if (slot > 0 && !hdr[blockIdx.y].undecided[slot - 1]) return;     // the previous launch settled everything
+    const size_t ib = (size_t)blockIdx.y * h * w;
+    const unsigned* ck = ckey + ib;
+    const unsigned* cl = cand + ib;
+    uint16_t* stt = state + ib;
+    const unsigned n = hdr[blockIdx.y].seg_end[seg];
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    SelGeom g;
+    g.h = h; g.w = w; g.r = r; g.side = 2 * r + 1; g.area = g.side * g.side; g.md2 = md2; g.inv_side = 1.0f / (float)g.side;
+    const bool small = g.area <= 64 * SEL_CH;
+    bool left = false;
+    for (unsigned c0 = wave; c0 < n; c0 += nwaves * 64u) {
+        const unsigned kmax = min(64u, (n - c0 + nwaves - 1) / nwaves);
+        unsigned long long pending = 0;
+        if (small) {
+            SelWin cur;
+            sel_fetch(g, stt, cl[c0], lane, cur);
+            unsigned p_next = kmax > 1 ? cl[c0 + nwaves] : 0u;
+            for (unsigned k = 0; k < kmax; ++k) {
+                SelWin nxt = cur;
+                const unsigned p1 = p_next;
+                if (k + 2 < kmax) p_next = cl[c0 + (k + 2) * nwaves];
+                if (k + 1 < kmax) sel_fetch(g, stt, p1, lane, nxt);
+                if (sel_eval(ck, stt, cur, lane, spins)) pending |= 1ull << k;
+                cur = nxt;
+            }
+        } else {
+            for (unsigned k = 0; k < kmax; ++k)
+                if (sel_visit_large(g, ck, stt, cl[c0 + k * nwaves], lane)) pending |= 1ull << k;
+        }
+        for (int pass = 1; pass < passes && pending; ++pass) {
+            unsigned long long m = pending;
+            while (m) {
+                const unsigned k = (unsigned)__builtin_ctzll(m);
+                m &= m - 1;
+                const unsigned p = cl[c0 + k * nwaves];
+                bool l;
+                if (small) { SelWin W; sel_fetch(g, stt, p, lane, W); l = sel_eval(ck, stt, W, lane, spins); }
+                else l = sel_visit_large(g, ck, stt, p, lane);
+                if (!l) pending &= ~(1ull << k);
+            }
+        }
+        if (pending) left = true;
+    }
+    if (left && lane == 0) hdr[blockIdx.y].undecided[slot] = 1u;     // flag only: a counter would be a contended atomic
+}
+
+// gather accepted candidates of the rank prefix as 64-bit keys (score bits << 32 | linear index);
+// also clears the rank counters the sort accumulates into (n_acc <= n)
+__global__ __launch_bounds__(256) void gather_accepted(const unsigned* __restrict__ ckey, int h, int w,
+                                                       GfttHdr* __restrict__ hdr, const uint16_t* __restrict__ state,
+                                                       const unsigned* __restrict__ cand, unsigned long long* __restrict__ keys,
+                                                       unsigned* __restrict__ rank, int take_all, int seg) {
+    const size_t ib = (size_t)blockIdx.y * h * w;
+    const unsigned n = hdr[blockIdx.y].seg_end[seg];
     const int lane = threadIdx.x & 63;
     for (unsigned c0 = (blockIdx.x * 256 + threadIdx.x) & ~63u; c0 < n; c0 += gridDim.x * 256) {
         const unsigned c = c0 + lane;
         bool ok = false;
         unsigned p = 0;
-        if (c < n) { p = cand[ib + c]; ok = take_all || state[ib + p] == 2; }
+        if (c < n) { p = cand[ib + c]; ok = take_all || (state[ib + p] & 3u) == 2u; rank[ib + c] = 0u; }
         const unsigned long long bal = __ballot(ok);
         if (!bal) continue;
         unsigned base = 0;
         const int leader = __ffsll((long long)bal) - 1;
         if (lane == leader) base = atomicAdd(&hdr[blockIdx.y].n_acc, (unsigned)__popcll(bal));
         base = (unsigned)__shfl((int)base, leader);
-        if (ok) keys[ib + base + __popcll(bal & ((1ull << lane) - 1))] =
-                    ((unsigned long long)__float_as_uint(score[ib + p]) << 32) | p;
+        if (ok) keys[ib + base + __popcll(bal & ((1ull << lane) - 1))] = ((unsigned long long)ckey[ib + p] << 32) | p;
     }
 }
 
@@ -327,6 +539,51 @@ __global__ __launch_bounds__(256) void emit_corners(const unsigned long long* __
     reinterpret_cast<float2*>(corners)[(size_t)blockIdx.y * out_stride + e] = make_float2((float)(p - y * w), (float)y);
 }
 
+// ---------------------------------------------------------------------------------------------
+// rank sort for up to RANK_MAX keys: rank(i) = number of larger keys (keys are unique), counted in
+// (256 keys) x (RANK_J keys) tiles over a 2-D grid; the inner operand is wave-uniform, so it comes
+// through scalar loads and the loop is one 64-bit compare + add per key.
+constexpr unsigned RANK_J = 128, RANK_MAX = 32768;
+__global__ __launch_bounds__(256) void rank_count(const unsigned long long* __restrict__ keys, const GfttHdr* __restrict__ hdr,
+                                                  size_t key_stride, unsigned* __restrict__ rank, size_t rank_stride) {
+    const unsigned n = hdr[blockIdx.z].n_acc;
+    if (n > RANK_MAX) return;                                     // the host runs the bitonic network instead
+    const unsigned long long* g = keys + (size_t)blockIdx.z * key_stride;
+    for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const unsigned i = i0 + threadIdx.x;
+        const unsigned long long mine = i < n ? g[i] : ~0ull;
+        for (unsigned j0 = blockIdx.y * RANK_J; j0 < n; j0 += gridDim.y * RANK_J) {
+            const unsigned jn = min(RANK_J, n - j0);
+            const unsigned long long* gj = g + j0;
+            unsigned cnt = 0, t = 0;
+            for (; t + 16 <= jn; t += 16) {                       // 16 keys = two s_load_dwordx16 per trip
+#pragma unroll
+                for (unsigned u = 0; u < 16; ++u) cnt += gj[t + u] > mine ? 1u : 0u;
+            }
+            for (; t < jn; ++t) cnt += gj[t] > mine ? 1u : 0u;
+            if (i < n && cnt) atomicAdd(&rank[(size_t)blockIdx.z * rank_stride + i], cnt);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __restrict__ keys, const GfttHdr* __restrict__ hdr,
+                                                   size_t key_stride, const unsigned* __restrict__ rank, size_t rank_stride,
+                                                   int w, float* __restrict__ corners, int out_stride, int max_out) {
+    const unsigned n = hdr[blockIdx.y].n_acc;
+    if (n > RANK_MAX) return;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned rk = rank[(size_t)blockIdx.y * rank_stride + i];
+        if (rk >= (unsigned)max_out) continue;
+        const unsigned p = (unsigned)(keys[(size_t)blockIdx.y * key_stride + i] & 0xffffffffull);
+        const unsigned y = p / (unsigned)w;
+        reinterpret_cast<float2*>(corners)[(size_t)blockIdx.y * out_stride + rk] = make_float2((float)(p - y * w), (float)y);
+    }
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 int ensure_ws(vofe_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return VOFE_OK;
     if (ctx->ws) { hipStreamSynchronize(ctx->stream); hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
@@ -366,27 +623,49 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
-    // workspace: hdr | score f32 | cand u32 | keys u64 | state u8
+    // workspace: hdr | bucket histogram | bucket cursors | keys u64 (unordered candidate list until the
+    // gather) | score f32 | bucket-ordered candidates u32 (ranks after the gather) | ckey u32 | state u16
     const size_t hdr_bytes = ((sizeof(GfttHdr) * batch + 255) / 256) * 256;
-    const size_t tot = hdr_bytes + batch * px * (4 + 4 + 8 + 1) + 1024;
+    const size_t hist_bytes = (size_t)batch * N_BUCKET * sizeof(unsigned);
+    const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024;
     int rc = ensure_ws(ctx, tot);
     if (rc) return rc;
     rc = ensure_pinned(ctx, (sizeof(GfttHdr) / 4) * (size_t)batch);
     if (rc) return rc;
     uint8_t* base = static_cast<uint8_t*>(ctx->ws);
     GfttHdr* hdr = reinterpret_cast<GfttHdr*>(base);
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + hdr_bytes);
-    float* score = reinterpret_cast<float*>(base + hdr_bytes + batch * px * 8);
-    unsigned* cand = reinterpret_cast<unsigned*>(base + hdr_bytes + batch * px * 12);
-    uint8_t* state = base + hdr_bytes + batch * px * 16;
+    unsigned* hist = reinterpret_cast<unsigned*>(base + hdr_bytes);
+    unsigned* cursor = reinterpret_cast<unsigned*>(base + hdr_bytes + hist_bytes);
+    uint8_t* maps = base + hdr_bytes + 2 * hist_bytes;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(maps);
+    unsigned* cand0 = reinterpret_cast<unsigned*>(maps);                     // stride 2*px words per image
+    float* score = reinterpret_cast<float*>(maps + batch * px * 8);
+    unsigned* cand = reinterpret_cast<unsigned*>(maps + batch * px * 12);
+    unsigned* ckey = reinterpret_cast<unsigned*>(maps + batch * px * 16);
+    uint16_t* state = reinterpret_cast<uint16_t*>(maps + batch * px * 20);
 
-    VOFE_HIP(hipMemsetAsync(hdr, 0, hdr_bytes, st));
+    const bool suppress = min_distance >= 1.0;
+    static const int sel_blocks = std::max(env_int("VOFE_SEL_BLOCKS", 1024), 1);
+    static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 2), 1), SELECT_ROUNDS);
+    static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 4), 1);
+    static const int sel_spins = std::max(env_int("VOFE_SEL_SPINS", 4), 0);
+    static const int sel_prefix = std::max(env_int("VOFE_SEL_PREFIX", 2), 1);
+    // first rank prefix: without suppression the best maxCorners candidates are the answer; with it,
+    // a few times maxCorners candidates usually hold maxCorners accepted ones (grown x2 otherwise)
+    unsigned seg_base = 0;
+    if (max_corners > 0) {
+        const unsigned long long b0 = (unsigned long long)max_corners * (suppress ? sel_prefix : 1);
+        seg_base = (unsigned)std::min<unsigned long long>(b0, 1u << 24);
+    }
+
+    VOFE_HIP(hipMemsetAsync(base, 0, hdr_bytes + hist_bytes, st));
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_compact, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st, score, h, w, quality, hdr,
-                       state, cand, d_mask);
-    const bool suppress = min_distance >= 1.0;
+    hipLaunchKernelGGL(nms_compact, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
+                       score, h, w, quality, hdr, state, ckey, cand0, 2 * px, hist, d_mask);
+    hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base);
+    hipLaunchKernelGGL(bucket_scatter, dim3(128, batch), dim3(256), 0, st, ckey, px, quality, hdr, cand0, 2 * px, cursor, cand);
     int r = 0;
     float md2 = 0.f;
     if (suppress) {
@@ -397,29 +676,58 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         if ((double)md2 < min_distance * min_distance) md2 = nextafterf(md2, INFINITY);
     }
     GfttHdr* hh = reinterpret_cast<GfttHdr*>(ctx->h_pinned);
-    const int sel_blocks = 512;
+    unsigned* rank = reinterpret_cast<unsigned*>(score);         // the score map is dead after nms_compact
+    int max_out = capacity;
+    if (max_corners > 0 && max_corners < max_out) max_out = max_corners;
+    const char* force = getenv("VOFE_GFTT_SORT");                 // "bitonic" forces the network (tests)
+    const bool use_rank = !(force && force[0] == 'b');
+    int seg = 0;
     for (int pass = 0;; ++pass) {
-        if (suppress) {
-            if (pass > 0) {
-                // clear the round counters and the accepted count, keep max_key / n_cand
-                for (int b = 0; b < batch; ++b) {
-                    VOFE_HIP(hipMemsetAsync(&hdr[b].n_acc, 0, sizeof(unsigned), st));
-                    VOFE_HIP(hipMemsetAsync(hdr[b].undecided, 0, sizeof(unsigned) * SELECT_ROUNDS, st));
-                }
+        if (pass > 0) {
+            // clear the round flags and the accepted count, keep the rest
+            for (int b = 0; b < batch; ++b) {
+                VOFE_HIP(hipMemsetAsync(&hdr[b].n_acc, 0, sizeof(unsigned), st));
+                VOFE_HIP(hipMemsetAsync(hdr[b].undecided, 0, sizeof(unsigned) * SELECT_ROUNDS, st));
             }
-            for (int round = 0; round < SELECT_ROUNDS; ++round)
-                hipLaunchKernelGGL(select_round, dim3(sel_blocks, batch), dim3(256), 0, st, score, h, w, r, md2, hdr, state,
-                                   cand, round);
         }
-        hipLaunchKernelGGL(gather_accepted, dim3(256, batch), dim3(256), 0, st, score, h, w, hdr, state, cand, keys,
-                           suppress ? 0 : 1);
+        if (suppress)
+            for (int round = 0; round < sel_launches; ++round)
+                hipLaunchKernelGGL(select_round, dim3(sel_blocks, batch), dim3(256), 0, st, ckey, h, w, r, md2, hdr, state,
+                                   cand, seg, sel_passes, sel_spins, round);
+        hipLaunchKernelGGL(gather_accepted, dim3(256, batch), dim3(256), 0, st, ckey, h, w, hdr, state, cand, keys,
+                           rank, suppress ? 0 : 1, seg);
+        if (use_rank && max_out > 0) {
+            // the sort runs speculatively behind the gather (sized by the device-side count), so the
+            // common case needs one host round trip per call
+            unsigned long long ub = seg_base ? ((unsigned long long)seg_base << seg) : px;
+            ub = std::min<unsigned long long>(std::min<unsigned long long>(ub + ub / 4, px), RANK_MAX);
+            const unsigned gi = (unsigned)((ub + 255) / 256), gj = (unsigned)((ub + RANK_J - 1) / RANK_J);
+            hipLaunchKernelGGL(rank_count, dim3(gi, gj, batch), dim3(256), 0, st, keys, hdr, px, rank, px);
+            hipLaunchKernelGGL(emit_ranked, dim3(gi, batch), dim3(256), 0, st, keys, hdr, px, rank, px, w, d_corners_xy,
+                               capacity, max_out);
+        }
         VOFE_HIP(hipMemcpyAsync(hh, hdr, sizeof(GfttHdr) * batch, hipMemcpyDeviceToHost, st));
         VOFE_HIP(hipStreamSynchronize(st));
-        bool done = true;
-        if (suppress)
-            for (int b = 0; b < batch; ++b)
-                if (hh[b].undecided[SELECT_ROUNDS - 1]) done = false;
-        if (done) break;
+        bool converged = true, enough = true;
+        for (int b = 0; b < batch; ++b) {
+            if (suppress && hh[b].undecided[sel_launches - 1]) converged = false;
+            if (hh[b].seg_end[seg] < hh[b].n_cand && (max_corners <= 0 || hh[b].n_acc < (unsigned)max_corners)) enough = false;
+        }
+        if (converged && enough) break;
+        if (converged && seg < N_SEG - 1) {
+            // every image's prefix is final: widen it to where the acceptance rate seen so far (which
+            // only falls with rank) would reach maxCorners, with 50 % head room
+            int next = seg + 1;
+            for (int b = 0; b < batch; ++b) {
+                if (hh[b].seg_end[seg] >= hh[b].n_cand || hh[b].n_acc >= (unsigned)max_corners) continue;
+                const double est = 1.5 * (double)hh[b].seg_end[seg] * (double)max_corners / (double)std::max(hh[b].n_acc, 1u);
+                int kx = seg + 1;
+                if (est > 0.5 * (double)hh[b].n_cand) kx = N_SEG - 1;         // most of the list anyway: take all
+                while (kx < N_SEG - 1 && (double)hh[b].seg_end[kx] < est) ++kx;
+                next = std::max(next, kx);
+            }
+            seg = next;
+        }
         if (pass > 1000000) { vofe_set_error("vofe_gftt: selection did not converge"); return VOFE_E_HIP; }
     }
     unsigned nmax = 0;
@@ -428,12 +736,12 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         nmax = n > nmax ? n : nmax;
         h_n_out[b] = (int)((max_corners > 0 && n > (unsigned)max_corners) ? (unsigned)max_corners : n);
     }
-    if (nmax == 0) return VOFE_OK;
-    int max_out = capacity;
-    if (max_corners > 0 && max_corners < max_out) max_out = max_corners;
+    if (nmax == 0 || max_out <= 0) return VOFE_OK;
     const unsigned chunks = (nmax + SORT_CH - 1) / SORT_CH;
     const size_t lds = (size_t)SORT_CH * 8;
-    if (chunks == 1) {
+    if (use_rank && nmax <= RANK_MAX) {
+        // already sorted and emitted by the speculative rank sort
+    } else if (chunks == 1) {
         unsigned len = 64;
         while (len < nmax) len <<= 1;
         hipLaunchKernelGGL(sort_local, dim3(1, batch), dim3(SORT_THREADS), (size_t)len * 8, st, keys, hdr, px, 0, 1, w,
