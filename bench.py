@@ -162,6 +162,16 @@ def main():
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # corner detection on the same geometry (one call per frame in the reference, continuous.py:380-385);
+    # not part of `value`, reported beside it.  Device-resident image in, corners copied back to the host.
+    gftt_calls = 100
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for i in range(gftt_calls):
+        fe.goodFeaturesToTrack(d_frames[i % N_FRAMES], args.points, 0.01, 7)
+    torch.cuda.synchronize()
+    gftt_us = (time.perf_counter() - t2) / gftt_calls * 1e6
+
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
     tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
     tsum = float(sum(tracked_per_step))
@@ -194,6 +204,8 @@ def main():
                        "frames_per_step": 1, "points": n, "sequences": world, "streams_per_gpu": S,
                        "parallelism": "replicas only (one sequence per GPU); %d independent pairs in flight per GPU" % S},
             "single_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
+            "gftt_us_per_call": round(gftt_us, 1),
+            "gftt_config": "goodFeaturesToTrack(1241x376, maxCorners=%d, qualityLevel=0.01, minDistance=7), serial calls" % n,
             "tracked_keypoints_per_s": round(tsum / elapsed, 1),
             "attempted_points_per_s": round(frames_total * n / elapsed, 1),
             "roofline": {

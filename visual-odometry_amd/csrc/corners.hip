@@ -26,7 +26,8 @@ constexpr int SORT_THREADS = 1024;
 constexpr int SELECT_ROUNDS = 8;                // rounds launched between host checks
 
 constexpr int N_SEG = 8;                        // growing rank prefixes tried by the selection
-constexpr int BUCKET_BITS = 13;
+constexpr int BUCKET_BITS = 14;                 // (bucket << 2 | state) must fit the u16 state map
+static_assert(BUCKET_BITS <= 14, "bucket index is stored in 14 bits");
 constexpr int N_BUCKET = 1 << BUCKET_BITS;      // score buckets of the coarse rank order (fine: few atomics collide)
 
 struct GfttHdr {
@@ -139,21 +140,26 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
         for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
         if ((tid & 63) == 0 && best) atomicMax(&sMax, best);
         __syncthreads();
-        if (tid == 0 && sMax) atomicMax(&hdr[blockIdx.z].max_key, sMax);
+        // same-address atomics serialise (~10 ns each): only blocks that can still raise the maximum issue one
+        if (tid == 0 && sMax > __hip_atomic_load(&hdr[blockIdx.z].max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hdr[blockIdx.z].max_key, sMax);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// threshold + 3x3 local maximum + compaction.
-// state map (u16 per pixel): 0 = no candidate, else (score bucket << 2) | state, state 1 = undecided.
+// threshold + 3x3 local maximum -> candidate maps + bucket histogram.
+// state map (u16 per pixel): 0 = no candidate, else (score bucket << 2) | state, state 1 = undecided;
+// ckey map: score bits of candidates, 0 elsewhere.  No list is built here: the bucket scatter below
+// reads the state map.  Histogram and scatter cursors exist in N_COPY copies chosen by pixel tile,
+// which divides the same-address atomic traffic of dense buckets.
 constexpr int NMS_ROWS = 8;      // rows per thread: a 256-thread block covers 64 x 32 pixels
-__global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ score, int h, int w, double quality,
-                                                   GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
-                                                   unsigned* __restrict__ ckey, unsigned* __restrict__ cand,
-                                                   size_t cand_stride, unsigned* __restrict__ hist,
-                                                   const uint8_t* __restrict__ mask) {
-    __shared__ unsigned s_wave[4];
-    __shared__ unsigned s_base;
+constexpr int N_COPY = 1;        // measured: more copies do not speed the atomics up, they only lengthen the scan
+__device__ __forceinline__ unsigned tile_copy(int x, int y) { return (unsigned)((x >> 6) + (y >> 5)) & (N_COPY - 1); }
+
+__global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, int h, int w, double quality,
+                                               const GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
+                                               unsigned* __restrict__ ckey, unsigned* __restrict__ hist,
+                                               const uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
     const int y0 = blockIdx.y * (4 * NMS_ROWS) + wv;
@@ -162,12 +168,12 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
     const unsigned mk = hdr[blockIdx.z].max_key;
     const float thr = gftt_threshold(mk, quality);
     const BucketMap bm = bucket_map(mk, thr);
-    unsigned* hs = hist + (size_t)blockIdx.z * N_BUCKET;
-    unsigned long long bal[NMS_ROWS];
-    unsigned total = 0;
+    unsigned* hs = hist + ((size_t)blockIdx.z * N_COPY + tile_copy(blockIdx.x * 64, blockIdx.y * (4 * NMS_ROWS))) * N_BUCKET;
+    if (x >= w) return;
 #pragma unroll
     for (int k = 0; k < NMS_ROWS; ++k) {
         const int y = y0 + 4 * k;
+        if (y >= h) break;
         bool is = false;
         float v = 0.f;
         if (mk && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
@@ -180,51 +186,36 @@ __global__ __launch_bounds__(256) void nms_compact(const float* __restrict__ sco
                 is = v >= m;
             }
         }
-        if (x < w && y < h) {
-            const unsigned d = is ? bucket_of(bm, __float_as_uint(v)) : 0u;
-            state[ib + (size_t)y * w + x] = is ? (uint16_t)((d << 2) | 1u) : (uint16_t)0;
-            ckey[ib + (size_t)y * w + x] = is ? __float_as_uint(v) : 0u;
-            if (is) atomicAdd(&hs[d], 1u);
-        }
-        bal[k] = __ballot(is);
-        total += (unsigned)__popcll(bal[k]);
-    }
-    if (lane == 0) s_wave[wv] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        s_base = t ? atomicAdd(&hdr[blockIdx.z].n_cand, t) : 0u;
-    }
-    __syncthreads();
-    unsigned pos = s_base;
-    for (int q = 0; q < wv; ++q) pos += s_wave[q];
-#pragma unroll
-    for (int k = 0; k < NMS_ROWS; ++k) {
-        if ((bal[k] >> lane) & 1ull)
-            cand[(size_t)blockIdx.z * cand_stride + pos + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned)((y0 + 4 * k) * w + x);
-        pos += (unsigned)__popcll(bal[k]);
+        const unsigned d = is ? bucket_of(bm, __float_as_uint(v)) : 0u;
+        state[ib + (size_t)y * w + x] = is ? (uint16_t)((d << 2) | 1u) : (uint16_t)0;
+        ckey[ib + (size_t)y * w + x] = is ? __float_as_uint(v) : 0u;
+        if (is) atomicAdd(&hs[d], 1u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive scan of the bucket histogram (one 1024-thread block per image, 4 buckets per thread)
-// -> scatter cursors, and the prefix lengths seg_end[k] = first bucket boundary >= min(n, base<<k)
-// (base = 0: everything).
+// exclusive scan of the bucket histogram in (bucket, copy) order: one 1024-thread block per image,
+// N_BUCKET/1024 consecutive buckets per thread -> scatter cursors, the candidate count, and the
+// prefix lengths seg_end[k] = first bucket boundary >= min(n, base << k) (base = 0: everything).
 __global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                     GfttHdr* __restrict__ hdr, unsigned base) {
     __shared__ unsigned s_w[16];
-    const unsigned* hs = hist + (size_t)blockIdx.x * N_BUCKET;
-    unsigned* cs = cursor + (size_t)blockIdx.x * N_BUCKET;
+    __shared__ unsigned s_n;
+    const unsigned* hs = hist + (size_t)blockIdx.x * N_COPY * N_BUCKET;
+    unsigned* cs = cursor + (size_t)blockIdx.x * N_COPY * N_BUCKET;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     constexpr int BPT = N_BUCKET / 1024;                 // consecutive buckets per thread
-    unsigned cnt[BPT], ex[BPT];
+    static_assert(BPT % 4 == 0, "uint4 access");
+    unsigned cnt[BPT][N_COPY];
     unsigned mine = 0;
 #pragma unroll
-    for (int i = 0; i < BPT / 4; ++i) {
-        const uint4 v = reinterpret_cast<const uint4*>(hs)[t * (BPT / 4) + i];
-        cnt[4 * i] = v.x; cnt[4 * i + 1] = v.y; cnt[4 * i + 2] = v.z; cnt[4 * i + 3] = v.w;
-        mine += v.x + v.y + v.z + v.w;
-    }
+    for (int c = 0; c < N_COPY; ++c)
+#pragma unroll
+        for (int i = 0; i < BPT / 4; ++i) {
+            const uint4 v = reinterpret_cast<const uint4*>(hs + (size_t)c * N_BUCKET)[t * (BPT / 4) + i];
+            cnt[4 * i][c] = v.x; cnt[4 * i + 1][c] = v.y; cnt[4 * i + 2][c] = v.z; cnt[4 * i + 3][c] = v.w;
+            mine += v.x + v.y + v.z + v.w;
+        }
     unsigned inc = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = (unsigned)__shfl_up((int)inc, o);
@@ -234,39 +225,65 @@ __global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__
     __syncthreads();
     unsigned off = 0;
     for (int q = 0; q < wv; ++q) off += s_w[q];
-    const unsigned n = hdr[blockIdx.x].n_cand;
+    if (t == 1023) { s_n = off + inc; hdr[blockIdx.x].n_cand = off + inc; }
+    __syncthreads();
+    const unsigned n = s_n;
     unsigned e0 = off + inc - mine;
+    unsigned bstart[BPT + 1];
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) { ex[i] = e0; e0 += cnt[i]; }
+    for (int i = 0; i < BPT; ++i) {
+        bstart[i] = e0;
 #pragma unroll
-    for (int i = 0; i < BPT / 4; ++i)
-        reinterpret_cast<uint4*>(cs)[t * (BPT / 4) + i] = make_uint4(ex[4 * i], ex[4 * i + 1], ex[4 * i + 2], ex[4 * i + 3]);
-    if (mine == 0 && t != 0) return;
+        for (int c = 0; c < N_COPY; ++c) { const unsigned k = cnt[i][c]; cnt[i][c] = e0; e0 += k; }
+    }
+    bstart[BPT] = e0;
+#pragma unroll
+    for (int c = 0; c < N_COPY; ++c)
+#pragma unroll
+        for (int i = 0; i < BPT / 4; ++i)
+            reinterpret_cast<uint4*>(cs + (size_t)c * N_BUCKET)[t * (BPT / 4) + i] =
+                make_uint4(cnt[4 * i][c], cnt[4 * i + 1][c], cnt[4 * i + 2][c], cnt[4 * i + 3][c]);
     for (int k = 0; k < N_SEG; ++k) {
         unsigned long long want = base ? ((unsigned long long)base << k) : (unsigned long long)n;
         if (k == N_SEG - 1 || want > n) want = n;
         const unsigned tk = (unsigned)want;
         if (tk == 0) { if (t == 0) hdr[blockIdx.x].seg_end[k] = 0; continue; }
-        if (!(ex[0] < tk && e0 >= tk)) continue;          // the boundary bucket is not among this thread's
+        if (!(bstart[0] < tk && e0 >= tk)) continue;          // the boundary bucket is not among this thread's
 #pragma unroll
         for (int i = 0; i < BPT; ++i)
-            if (cnt[i] && ex[i] < tk && ex[i] + cnt[i] >= tk) hdr[blockIdx.x].seg_end[k] = ex[i] + cnt[i];
+            if (bstart[i] < tk && bstart[i + 1] >= tk) hdr[blockIdx.x].seg_end[k] = bstart[i + 1];
     }
 }
 
-// bucket-ordered candidate list
-__global__ __launch_bounds__(256) void bucket_scatter(const unsigned* __restrict__ ckey, size_t px, double quality,
-                                                      const GfttHdr* __restrict__ hdr, const unsigned* __restrict__ cand,
-                                                      size_t cand_stride, unsigned* __restrict__ cursor,
-                                                      unsigned* __restrict__ sorted) {
-    const unsigned n = hdr[blockIdx.y].n_cand;
-    const unsigned mk = hdr[blockIdx.y].max_key;
-    const BucketMap bm = bucket_map(mk, gftt_threshold(mk, quality));
-    for (unsigned c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
-        const unsigned p = cand[(size_t)blockIdx.y * cand_stride + c];
-        const unsigned d = bucket_of(bm, ckey[(size_t)blockIdx.y * px + p]);
-        const unsigned pos = atomicAdd(&cursor[(size_t)blockIdx.y * N_BUCKET + d], 1u);
-        sorted[(size_t)blockIdx.y * px + pos] = p;
+// bucket-ordered candidate list, straight from the state map (8 pixels per thread)
+__global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict__ state, int h, int w,
+                                                      unsigned* __restrict__ cursor, unsigned* __restrict__ sorted) {
+    const size_t px = (size_t)h * w;
+    const uint16_t* stt = state + (size_t)blockIdx.y * px;
+    unsigned* cs = cursor + (size_t)blockIdx.y * N_COPY * N_BUCKET;
+    // the state base is 16-byte aligned; image b starts b*px elements in, so groups of 8 are shifted
+    // to stay aligned in memory (the first group of an image may start before element 0)
+    const long long mis = (long long)(((size_t)blockIdx.y * px) & 7);
+    for (long long e0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8 - mis; e0 < (long long)px;
+         e0 += (long long)gridDim.x * 256 * 8) {
+        unsigned v[8];
+        if (e0 >= 0 && e0 + 8 <= (long long)px) {
+            const uint4 q = *reinterpret_cast<const uint4*>(stt + e0);
+            v[0] = q.x & 0xffffu; v[1] = q.x >> 16; v[2] = q.y & 0xffffu; v[3] = q.y >> 16;
+            v[4] = q.z & 0xffffu; v[5] = q.z >> 16; v[6] = q.w & 0xffffu; v[7] = q.w >> 16;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (e0 + i >= 0 && e0 + i < (long long)px) ? stt[e0 + i] : 0u;
+        }
+        if (!(v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | v[7])) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!v[i]) continue;
+            const unsigned p = (unsigned)(e0 + i);
+            const int y = (int)(p / (unsigned)w), x = (int)(p - (unsigned)y * w);
+            const unsigned pos = atomicAdd(&cs[(size_t)tile_copy(x, y) * N_BUCKET + (v[i] >> 2)], 1u);
+            sorted[(size_t)blockIdx.y * px + pos] = p;
+        }
     }
 }
 
@@ -623,11 +640,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
-    // workspace: hdr | bucket histogram | bucket cursors | keys u64 (unordered candidate list until the
-    // gather) | score f32 | bucket-ordered candidates u32 (ranks after the gather) | ckey u32 | state u16
+    // workspace: hdr | bucket histograms | bucket cursors | keys u64 | score f32 | bucket-ordered candidates u32 (ranks after the gather) | ckey u32 | state u16
     const size_t hdr_bytes = ((sizeof(GfttHdr) * batch + 255) / 256) * 256;
-    const size_t hist_bytes = (size_t)batch * N_BUCKET * sizeof(unsigned);
-    const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024;
+    const size_t hist_bytes = (size_t)batch * N_COPY * N_BUCKET * sizeof(unsigned);
+    const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
     int rc = ensure_ws(ctx, tot);
     if (rc) return rc;
     rc = ensure_pinned(ctx, (sizeof(GfttHdr) / 4) * (size_t)batch);
@@ -638,11 +654,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     unsigned* cursor = reinterpret_cast<unsigned*>(base + hdr_bytes + hist_bytes);
     uint8_t* maps = base + hdr_bytes + 2 * hist_bytes;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(maps);
-    unsigned* cand0 = reinterpret_cast<unsigned*>(maps);                     // stride 2*px words per image
     float* score = reinterpret_cast<float*>(maps + batch * px * 8);
     unsigned* cand = reinterpret_cast<unsigned*>(maps + batch * px * 12);
     unsigned* ckey = reinterpret_cast<unsigned*>(maps + batch * px * 16);
-    uint16_t* state = reinterpret_cast<uint16_t*>(maps + batch * px * 20);
+    uint16_t* state = reinterpret_cast<uint16_t*>(maps + ((batch * px * 20 + 15) & ~(size_t)15));   // 16-byte aligned
 
     const bool suppress = min_distance >= 1.0;
     static const int sel_blocks = std::max(env_int("VOFE_SEL_BLOCKS", 1024), 1);
@@ -662,10 +677,11 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_compact, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
-                       score, h, w, quality, hdr, state, ckey, cand0, 2 * px, hist, d_mask);
+    hipLaunchKernelGGL(nms_map, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
+                       score, h, w, quality, hdr, state, ckey, hist, d_mask);
     hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base);
-    hipLaunchKernelGGL(bucket_scatter, dim3(128, batch), dim3(256), 0, st, ckey, px, quality, hdr, cand0, 2 * px, cursor, cand);
+    hipLaunchKernelGGL(bucket_scatter, dim3((unsigned)std::min<size_t>((px + 2047) / 2048, 2048), batch), dim3(256), 0, st,
+                       state, h, w, cursor, cand);
     int r = 0;
     float md2 = 0.f;
     if (suppress) {
@@ -728,7 +744,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             }
             seg = next;
         }
-        if (pass > 1000000) { vofe_set_error("vofe_gftt: selection did not converge"); return VOFE_E_HIP; }
+        if (pass > 4096) { vofe_set_error("vofe_gftt: selection did not converge"); return VOFE_E_HIP; }
     }
     unsigned nmax = 0;
     for (int b = 0; b < batch; ++b) {
