@@ -301,3 +301,29 @@ def test_gftt_bad_arguments_raise(fe):
             fe.goodFeaturesToTrack(a, *args)
     with pytest.raises(error):
         fe.goodFeaturesToTrack(a.astype(np.float32), 10, 0.01, 5)
+
+
+# ------------------------------------------------------------------ frame-level tracker
+def test_sequence_tracker_matches_per_call_path(fe):
+    """One pyramid per frame + both point sets in one launch == ContinuousVO._track_keypoints per set."""
+    from visual_odometry_amd import SequenceTracker
+    H, W = 188, 310
+    frames = _seq(H, W, 21, 4)
+    trk = SequenceTracker(H, W, winSize=(21, 21), maxLevel=3, frontend=fe)
+    trk.reset(frames[0])
+    rng = np.random.default_rng(5)
+    land = (rng.random((2, 150)) * [[W - 1], [H - 1]]).astype(np.float32)
+    cand = (rng.random((2, 70)) * [[W - 1], [H - 1]]).astype(np.float32)
+    for t in range(1, 4):
+        (lp, ls, le), (cp, cs, ce), (ep, es, ee) = trk.track(frames[t], land, cand, np.empty((2, 0)))
+        for pts, got in ((land, (lp, ls, le)), (cand, (cp, cs, ce))):
+            ref = oracle.track_keypoints(pts, frames[t - 1], frames[t], nthreads=8)
+            assert np.array_equal(got[1], ref[1])
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+        assert ep.shape == (2, 0) and es.shape == (0,) and ee.shape == (0,)
+        det = trk.detect(200, 0.01, 7)
+        assert np.array_equal(det, oracle.goodFeaturesToTrack(frames[t], 200, 0.01, 7))
+        land, cand = lp[:, ls == 1], cp[:, cs == 1]        # carry the survivors, as process_frame does
+    trk.close()
+    with pytest.raises(Exception):
+        SequenceTracker(H, W, frontend=fe).track(frames[0], land)

@@ -15,7 +15,10 @@ OPTFLOW_LK_GET_MIN_EIGENVALS = 8
 def __getattr__(name):
     # torch-dependent names are resolved lazily so that CPU-only tooling can import the package
     if name in ("FrontEnd", "Pyramid", "goodFeaturesToTrack", "calcOpticalFlowPyrLK", "track_keypoints",
-                "default_frontend", "SequenceTracker"):
+                "default_frontend"):
         from . import frontend
         return getattr(frontend, name)
+    if name == "SequenceTracker":
+        from .sequence import SequenceTracker
+        return SequenceTracker
     raise AttributeError(name)

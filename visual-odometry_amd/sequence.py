@@ -1,0 +1,96 @@
+"""Frame-level tracker with a cached pyramid (first "next" row).
+
+The reference calls cv2.calcOpticalFlowPyrLK four times per frame (continuous.py:145-151 inside
+_track_keypoints, called for landmarks at continuous.py:180 and for candidates at continuous.py:330),
+and every call rebuilds the pyramids of both images.  Frames arrive in order, so the pyramid of the
+previous frame is still valid: SequenceTracker keeps a two-slot pyramid ring, builds ONE pyramid per
+new frame and tracks all point sets of the frame (landmarks and candidates) forward + backward with
+the forward-backward check in ONE launch.  Results per set are the same triple, bit for bit, that
+FrontEnd.track_keypoints (= ContinuousVO._track_keypoints) returns.
+
+Host side only: it is built from the C-ABI entry points vofe_pyramid_build / vofe_track_fb / vofe_gftt.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import error
+from .frontend import FrontEnd, Pyramid, _DEFAULT_CRITERIA
+
+
+class SequenceTracker:
+    def __init__(self, height, width, winSize=(21, 21), maxLevel=3, criteria=_DEFAULT_CRITERIA,
+                 minEigThreshold=1e-3, fb_thresh=1.0, frontend=None, device=0):
+        self.fe = frontend if frontend is not None else FrontEnd(device)
+        self._own_fe = frontend is None
+        self.h, self.w = int(height), int(width)
+        self.criteria = (int(criteria[0]), int(criteria[1]), float(criteria[2]))
+        self.min_eig = float(minEigThreshold)
+        self.fb_thresh = float(fb_thresh)
+        self.pyr = Pyramid(self.fe, 2, self.h, self.w, winSize, maxLevel, True)
+        self.frame_index = -1                     # index of the frame held in slot frame_index & 1
+        self._img = [None, None]                  # device images of the two slots (for detect())
+
+    # -- frames ----------------------------------------------------------------------------------
+    def _push(self, img):
+        d = self.fe.to_device(img)
+        if tuple(d.shape) != (self.h, self.w):
+            raise error(-1, "frame size %s does not match the tracker geometry %s" % (tuple(d.shape), (self.h, self.w)))
+        self.frame_index += 1
+        slot = self.frame_index & 1
+        self.pyr.build(d.reshape(1, self.h, self.w), slot)
+        self._img[slot] = d
+        return slot
+
+    def reset(self, img):
+        """Start a sequence with its first frame (no tracking)."""
+        self.frame_index = -1
+        self._push(img)
+
+    def track(self, img_current, *point_sets):
+        """Track every (2,N) point set of the previous frame into img_current.
+
+        Returns one (tracked (2,N) f32, status (N,) u8, err (N,) f32) triple per set, identical to
+        track_keypoints(points, img_prev, img_current); empty sets give the empty triple of
+        continuous.py:131-132.  img_current becomes the previous frame of the next call."""
+        if self.frame_index < 0:
+            raise error(-1, "SequenceTracker.track before reset()")
+        prev_slot = self.frame_index & 1
+        next_slot = self._push(img_current)
+        sets = [np.asarray(p) for p in point_sets]
+        flat = [np.ascontiguousarray(p.T.reshape(-1, 2).astype(np.float32)) for p in sets if p.size]
+        n = sum(f.shape[0] for f in flat)
+        if n:
+            fe = self.fe
+            d_prev = torch.from_numpy(np.concatenate(flat, 0)).to(fe.device)
+            d_next = torch.empty_like(d_prev)
+            d_st = torch.empty(n, dtype=torch.uint8, device=fe.device)
+            d_err = torch.empty(n, dtype=torch.float32, device=fe.device)
+            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, d_prev.data_ptr(), None,
+                                          d_next.data_ptr(), d_st.data_ptr(), d_err.data_ptr(), n, self.criteria[0],
+                                          self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
+            nxt, st, err = d_next.cpu().numpy(), d_st.cpu().numpy(), d_err.cpu().numpy()
+        out, o = [], 0
+        for p in sets:
+            if p.size == 0:
+                out.append((np.empty((2, 0)), np.empty((0,), dtype=np.uint8), np.empty((0,), dtype=np.float32)))
+                continue
+            k = p.T.reshape(-1, 2).shape[0]
+            out.append((nxt[o:o + k].T, st[o:o + k], err[o:o + k]))
+            o += k
+        return out
+
+    def detect(self, maxCorners, qualityLevel, minDistance, mask=None, useHarrisDetector=False, k=0.04):
+        """cv2.goodFeaturesToTrack on the current frame (continuous.py:380-385) without another upload."""
+        if self.frame_index < 0:
+            raise error(-1, "SequenceTracker.detect before reset()")
+        return self.fe.goodFeaturesToTrack(self._img[self.frame_index & 1], maxCorners, qualityLevel, minDistance,
+                                           mask=mask, useHarrisDetector=useHarrisDetector, k=k)
+
+    def close(self):
+        if self.pyr is not None:
+            self.pyr.free()
+            self.pyr = None
+        if self._own_fe and self.fe is not None:
+            self.fe.close()
+        self.fe = None
