@@ -1,6 +1,6 @@
 """Times the fused fwd+bwd LK launch alone (HIP events) and checks bit-exactness vs the oracle."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '/root/repo')
 import oracle
 from visual_odometry_amd import synthetic, _lib
 from visual_odometry_amd.frontend import FrontEnd, Pyramid

@@ -123,6 +123,22 @@ def test_lk_negative_fourth_bilinear_weight(fe):
     assert exact
 
 
+def test_lk_extreme_contrast_takes_the_wide_sum_path(fe):
+    """0/255 block noise: per-lane partial sums exceed 2^25, so the window sums leave the int32 fast
+    path and must still equal the oracle's exact int64 sums (large windows make it certain)."""
+    rng = np.random.default_rng(17)
+    blocks = (rng.random((60, 80)) > 0.5).astype(np.uint8) * 255
+    a = np.kron(blocks, np.ones((4, 4), np.uint8))
+    b = np.roll(a, (1, 2), axis=(0, 1))
+    b[::7, ::5] ^= 255
+    pts = (rng.random((300, 2)) * [319, 239]).astype(np.float32)
+    for win, lvl in (((21, 21), 2), ((41, 41), 1), ((64, 64), 0)):
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, None, win, lvl, (3, 30, 0.01), 0, 1e-4, nthreads=8)
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, None, win, lvl, (3, 30, 0.01), 0, 1e-4)
+        assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
+        assert s1.sum() > 0
+
+
 def test_lk_counters(fe):
     import torch
     from visual_odometry_amd import _lib

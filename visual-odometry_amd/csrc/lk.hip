@@ -84,6 +84,14 @@ __device__ __forceinline__ float wave_sum_to_float(int v) {
     return (float)((long long)hi * 65536 + (long long)lo);
 }
 
+// Common case: every lane's partial is below 2^25 in magnitude, so the 64-lane total fits int32 and
+// one DPP reduction per value replaces the two half-word reductions (same exact integer, same
+// single rounding).  The test is wave-uniform.
+__device__ __forceinline__ bool partials_fit(int a, int b, int c = 0) {
+    const unsigned m = (unsigned)abs(a) | (unsigned)abs(b) | (unsigned)abs(c);
+    return !__any(m >= (1u << 25));
+}
+
 struct Wts { unsigned w0, w1; int w00, w01, w10, w11; };
 __device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int iy) {
     const float a = fx - (float)ix, b = fy - (float)iy;
@@ -253,7 +261,11 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 Dval[k] = (ix & 0xffff) | (iy << 16);
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
             }
-            fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
+            if (partials_fit(a11, a12, a22)) {
+                fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
+            } else {
+                fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
+            }
         }
         STAMP_END(0);
         const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -305,7 +317,10 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 b2 += diff * (Dval[k] >> 16);
             }
             STAMP_END(3);
-            const float fb1 = wave_sum_to_float(b1) * FLT_SCALE, fb2 = wave_sum_to_float(b2) * FLT_SCALE;
+            float fb1, fb2;
+            if (partials_fit(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
+            else { fb1 = wave_sum_to_float(b1); fb2 = wave_sum_to_float(b2); }
+            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
             STAMP_END(4);
             const float dx = (A12 * fb2 - A22 * fb1) * Dd;
             const float dy = (A12 * fb1 - A11 * fb2) * Dd;
