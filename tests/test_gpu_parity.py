@@ -23,8 +23,11 @@ def _seq(h, w, seed, n=2):
 @pytest.mark.parametrize("h,w,win,levels", [(376, 1241, (21, 21), 3), (97, 131, (11, 11), 3),
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
                                             (33, 250, (5, 7), 2)])
-def test_pyramid_and_scharr_bit_exact(fe, h, w, win, levels):
+@pytest.mark.parametrize("path", ["fused", "levels"])
+def test_pyramid_and_scharr_bit_exact(fe, monkeypatch, h, w, win, levels, path):
+    """Both build paths (one fused launch for small frames, per-level kernels for large ones)."""
     import torch
+    monkeypatch.setenv("VOFE_PYRAMID", path)
     from visual_odometry_amd.frontend import Pyramid
     imgs = _seq(h, w, seed=h + w, n=2)
     pyr = Pyramid(fe, 2, h, w, win, levels, True)
@@ -42,6 +45,22 @@ def test_pyramid_and_scharr_bit_exact(fe, h, w, win, levels):
             exp = np.pad(ref, ((win[1], win[1]), (win[0], win[0])), mode="reflect")
             assert np.array_equal(pad, exp), "REFLECT_101 border of level %d differs" % lvl
     pyr.free()
+
+
+def test_pyramid_large_frame_default_path(fe):
+    """Above 3 Mpx per build the per-level kernels are chosen by default (6 levels also exceed the fused plan)."""
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    h, w = 1300, 2500
+    img = _seq(h, w, seed=2, n=1)[0]
+    for levels in (3, 6):
+        pyr = Pyramid(fe, 1, h, w, (21, 21), levels, True)
+        pyr.build(torch.from_numpy(img).cuda(), 0)
+        for lvl in range(pyr.levels):
+            ref = oracle.pyramid_level(img, lvl)
+            got, der = pyr.download(0, lvl, deriv=True)
+            assert np.array_equal(got, ref) and np.array_equal(der, oracle.scharr(ref))
+        pyr.free()
 
 
 def test_pyramid_rebuild_other_slot(fe):

@@ -306,7 +306,13 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
                         int pitch, size_t img_stride) {
     hipStream_t st = ctx->stream;
     const int ww = pyr->win_w, wh = pyr->win_h;
-    if (pyr->levels <= FUSE_MAX_LEVELS && !getenv("VOFE_PYRAMID_UNFUSED")) {
+    // Small frames are launch/latency bound: one fused launch for all levels wins (KITTI pair 21.6 vs 30 us).
+    // Large frames are bandwidth bound and the halo recompute of the fused kernel costs more than the extra
+    // launches (3840x2160 pair: 134 us fused vs 77 us per-level), so they take the per-level kernels.
+    const char* force = getenv("VOFE_PYRAMID");          // "fused" / "levels" force one path (tests, measurements)
+    const bool small = (long long)pyr->height * pyr->width * count <= 3000000ll;
+    const bool fused = force ? force[0] == 'f' : small;
+    if (pyr->levels <= FUSE_MAX_LEVELS && fused) {
         // fused path: 2 launches (interiors + Scharr, then border bands)
         FusePlan P;
         P.levels = pyr->levels;
