@@ -147,6 +147,140 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// score map, register-strip version (frames with w >= 8, h >= 2): one thread owns 4 adjacent columns
+// and walks RS output rows; no LDS.  Per image row it loads the 8 bytes covering columns x-2..x+5 with
+// one unaligned load, keeps a 3-row ring of the horizontal Sobel terms, a 3-row ring of the f64
+// horizontal box sums of the three products, and emits one row of 4 scores per step.  Borders follow
+// the oracle exactly: REFLECT_101 on the image for the Sobel taps, REFLECT_101 on the product maps
+// for the box sums (column -1 := column 1, column w := column w-2, same for rows).  All float/double
+// operations are the ones of corner_score_f32 above, in the same order.
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+
+template <int RS>
+__global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restrict__ img, int h, int w, int pitch,
+                                                          size_t img_stride, int harris, float kf,
+                                                          float* __restrict__ score, GfttHdr* __restrict__ hdr,
+                                                          const uint8_t* __restrict__ mask) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = ((int)blockIdx.x * 64 + lane) * 4;
+    const int y0 = ((int)blockIdx.y * 4 + wv) * RS;
+    if (y0 >= h) return;                                  // whole wave (no block barrier below)
+    const uint8_t* im = img + (size_t)blockIdx.z * img_stride;
+    const bool live = x < w;
+    const int xa = min(max(x - 2, 0), w - 8);
+    const int sh = live ? (x - 2 - xa) * 8 : 0;           // -16, 0, 8 .. 40 bits
+    const int jw = w - 1 - x;                             // local index of the last image column (0..3: right border thread)
+    const bool lb = (x == 0);
+    const float s1 = (float)(1.0 / 3060.0), s2 = (float)(2.0 / 3060.0);
+
+    unsigned long long bits[RS + 4];
+#pragma unroll
+    for (int t = 0; t < RS + 4; ++t) {
+        int a = y0 - 2 + t;
+        a = a < 0 ? -a : a;
+        a = a >= h ? 2 * h - 2 - a : a;
+        a = min(max(a, 0), h - 1);                        // rows that only feed unused outputs
+        bits[t] = *reinterpret_cast<const __attribute__((address_space(1))) u64_unaligned*>(
+            (const __attribute__((address_space(1))) uint8_t*)(im + (size_t)a * pitch + xa));
+    }
+
+    float hd[3][6], hs[3][6];
+    double rsum[3][3][4];
+    unsigned best = 0;
+#pragma unroll
+    for (int t = 0; t < RS + 4; ++t) {
+        // ---- horizontal Sobel terms of image row y0-2+t
+        {
+            const unsigned long long v = sh < 0 ? bits[t] << 16 : bits[t] >> sh;
+            const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+            float f[8];
+            f[0] = (float)(lo & 0xffu); f[1] = (float)((lo >> 8) & 0xffu); f[2] = (float)((lo >> 16) & 0xffu); f[3] = (float)(lo >> 24);
+            f[4] = (float)(hi & 0xffu); f[5] = (float)((hi >> 8) & 0xffu); f[6] = (float)((hi >> 16) & 0xffu); f[7] = (float)(hi >> 24);
+            if (lb) f[1] = f[3];                          // I[-1] = I[1]
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj)                // jw == 4: the last column is this thread's right halo
+                if (jw == jj) f[jj + 3] = f[jj + 1];      // I[w] = I[w-2]
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                hd[t % 3][c] = f[c + 2] - f[c];
+                hs[t % 3][c] = s2 * f[c + 1] + s1 * (f[c] + f[c + 2]);
+            }
+        }
+        if (t < 2) continue;
+        // ---- products of row v = y0-3+t (image rows t-2, t-1, t of the ring) and their f64 row sums
+        {
+            const int top = (t - 2) % 3, mid = (t - 1) % 3, bot = t % 3;
+            float pxx[6], pxy[6], pyy[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float dx = s2 * hd[mid][c] + s1 * (hd[top][c] + hd[bot][c]);
+                const float dy = hs[bot][c] - hs[top][c];
+                pxx[c] = dx * dx; pxy[c] = dx * dy; pyy[c] = dy * dy;
+            }
+            if (lb) { pxx[0] = pxx[2]; pxy[0] = pxy[2]; pyy[0] = pyy[2]; }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jw == jj) { pxx[jj + 2] = pxx[jj]; pxy[jj + 2] = pxy[jj]; pyy[jj + 2] = pyy[jj]; }
+            const int slot = t % 3;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                rsum[slot][0][o] = ((double)pxx[o] + (double)pxx[o + 1]) + (double)pxx[o + 2];
+                rsum[slot][1][o] = ((double)pxy[o] + (double)pxy[o + 1]) + (double)pxy[o + 2];
+                rsum[slot][2][o] = ((double)pyy[o] + (double)pyy[o + 1]) + (double)pyy[o + 2];
+            }
+        }
+        if (t < 4) continue;
+        // ---- output row y = y0-4+t from the row sums of rows y-1, y, y+1 (slots t-2, t-1, t)
+        const int y = y0 - 4 + t;
+        if (y >= h) break;                                // uniform
+        const int sa = (y == 0) ? t % 3 : (t - 2) % 3;    // row -1 := row 1
+        const int sb = (t - 1) % 3;
+        const int sc = (y == h - 1) ? (t - 2) % 3 : t % 3; // row h := row h-2
+        float out[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            // slot selection is uniform; written as selects so that the ring stays in registers
+            float c[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const double A = (y == 0) ? rsum[t % 3][ch][o] : rsum[(t - 2) % 3][ch][o];
+                const double B = rsum[(t - 1) % 3][ch][o];
+                const double C = (y == h - 1) ? rsum[(t - 2) % 3][ch][o] : rsum[t % 3][ch][o];
+                c[ch] = (float)((A + B) + C);
+            }
+            if (!harris) {
+                const float a = c[0] * 0.5f, b = c[1], cc = c[2] * 0.5f;
+                out[o] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+            } else {
+                out[o] = (c[0] * c[2] - c[1] * c[1]) - kf * ((c[0] + c[2]) * (c[0] + c[2]));
+            }
+        }
+        (void)sa; (void)sb; (void)sc;
+        if (live) {
+            float* dst = score + ((size_t)blockIdx.z * h + y) * w + x;
+            if (x + 3 < w) {
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                f4u q; q.x = out[0]; q.y = out[1]; q.z = out[2]; q.w = out[3];
+                *reinterpret_cast<f4u*>(dst) = q;
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) if (x + o < w) dst[o] = out[o];
+            }
+            if (hdr) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (x + o < w && (!mask || mask[(size_t)y * w + x + o])) best = max(best, float_key(out[o]));
+            }
+        }
+    }
+    if (hdr) {
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+        if (lane == 0 && best > __hip_atomic_load(&hdr[blockIdx.z].max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hdr[blockIdx.z].max_key, best);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // threshold + 3x3 local maximum -> candidate maps + bucket histogram.
 // state map (u16 per pixel): 0 = no candidate, else (score bucket << 2) | state, state 1 = undecided;
 // ckey map: score bits of candidates, 0 elsewhere.  No list is built here: the bucket scatter below
@@ -624,10 +758,34 @@ int ensure_pinned(vofe_ctx* ctx, size_t ints) {
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
                              unsigned* d_hdr, const uint8_t* d_mask) {
-    dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
-    if (grid.y > 65535 || grid.z > 65535) { vofe_set_error("corner_score: image or batch too large"); return VOFE_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(corner_score_f32, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
-                       d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+    if (batch > 65535) { vofe_set_error("corner_score: batch too large"); return VOFE_E_UNSUPPORTED; }
+    const char* force = getenv("VOFE_CORNER_SCORE");             // "tile" forces the LDS-tile kernel (tests)
+    if (w >= 8 && h >= 2 && !(force && force[0] == 't')) {
+        // strips of 8 rows; 4 rows while that leaves SIMDs without a wave (small frames are latency bound)
+        const long long waves8 = (long long)((w + 255) / 256) * ((h + 7) / 8) * batch;
+        if (waves8 >= 3072) {
+            // more 8-row waves than the chip holds at once (3 per SIMD at this register count): 16-row strips
+            // halve the wave count and trim the 4 halo rows per strip
+            dim3 grid((w + 255) / 256, (h + 63) / 64, batch);
+            if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+            hipLaunchKernelGGL(corner_score_strip<16>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
+                               d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+        } else if (waves8 >= 1024) {
+            dim3 grid((w + 255) / 256, (h + 31) / 32, batch);
+            if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+            hipLaunchKernelGGL(corner_score_strip<8>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
+                               d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+        } else {
+            dim3 grid((w + 255) / 256, (h + 15) / 16, batch);
+            hipLaunchKernelGGL(corner_score_strip<4>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
+                               d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+        }
+    } else {
+        dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
+        if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+        hipLaunchKernelGGL(corner_score_f32, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
+                           d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "corner_score launch");
     return VOFE_OK;
