@@ -168,6 +168,7 @@ struct FusePlan {
     int levels, tw, th, halo;
     int n[FUSE_MAX_LEVELS], m[FUSE_MAX_LEVELS], off[FUSE_MAX_LEVELS];
 };
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
 __device__ __forceinline__ int refl1(int c, int n) {      // one reflection is enough here (|overshoot| <= 2)
     if (n == 1) return 0;
     return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c);
@@ -185,18 +186,42 @@ __global__ __launch_bounds__(1024) void pyramid_fused(const uint8_t* __restrict_
 #pragma unroll
     for (int k = FUSE_MAX_LEVELS - 1; k >= 1; --k)
         if (k <= T) { lox[k - 1] = 2 * lox[k] - 2; loy[k - 1] = 2 * loy[k] - 2; }
+    lox[0] &= ~3;                      // dword-aligned origin of the level-0 region (P.n[0] is widened to match)
     const int slot = slot0 + (int)blockIdx.z;
-    {   // level-0 region from the caller's image
+    {   // level-0 region from the caller's image.  The region's x origin is rounded down to a multiple of 4
+        // and its pitch P.n[0] is a multiple of 4, so it is filled with dwords: every thread first issues all
+        // of its (unaligned) global loads, then writes them to LDS -- one memory latency for the whole region
+        // instead of one per row batch.
         const VofeLevel L = lv[0];
         const uint8_t* im = src + (size_t)blockIdx.z * img_stride;
-        uint8_t* r0 = R + P.off[0];
-        for (int j = ty; j < P.m[0]; j += nty) {
-            const int cy = loy[0] + j;
-            if (cy < 0 || cy >= L.h) continue;
-            const uint8_t* row = im + (size_t)cy * spitch;
-            for (int i = tx; i < P.n[0]; i += 32) {
-                const int cx = lox[0] + i;
-                if (cx >= 0 && cx < L.w) r0[j * P.n[0] + i] = row[cx];
+        unsigned* r0 = reinterpret_cast<unsigned*>(R + P.off[0]);
+        const int dwr = P.n[0] >> 2, total = dwr * P.m[0];
+        const float inv_dwr = 1.0f / (float)dwr;
+        constexpr int U = 4;
+        for (int base = (int)threadIdx.x; base < total; base += 1024 * U) {
+            unsigned v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 1024;
+                v[u] = 0u;
+                if (e >= total) continue;
+                const int j = (int)(((float)e + 0.5f) * inv_dwr);          // e / dwr, exact for e < 2^20
+                const int cx = lox[0] + 4 * (e - j * dwr), cy = loy[0] + j;
+                if (cy < 0 || cy >= L.h) continue;
+                const uint8_t* row = im + (size_t)cy * spitch;
+                if (cx >= 0 && cx + 3 < L.w) {
+                    v[u] = *reinterpret_cast<const __attribute__((address_space(1))) u32_unaligned*>(
+                        (const __attribute__((address_space(1))) uint8_t*)(row + cx));
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (cx + b >= 0 && cx + b < L.w) v[u] |= (unsigned)row[cx + b] << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 1024;
+                if (e < total) r0[e] = v[u];
             }
         }
     }
@@ -321,6 +346,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         P.halo = pyr->with_deriv ? 1 : 0;
         P.n[T] = P.tw + 2 * P.halo; P.m[T] = P.th + 2 * P.halo;
         for (int k = T; k >= 1; --k) { P.n[k - 1] = 2 * P.n[k] + 3; P.m[k - 1] = 2 * P.m[k] + 3; }
+        P.n[0] = (P.n[0] + 3 + 3) & ~3;       // level-0 region: origin rounded down to x % 4 == 0, dword pitch
         int off = 0;
         for (int k = 0; k <= T; ++k) { P.off[k] = off; off += (P.n[k] * P.m[k] + 15) / 16 * 16; }
         for (int k = T + 1; k < FUSE_MAX_LEVELS; ++k) { P.n[k] = P.m[k] = P.off[k] = 0; }
