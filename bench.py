@@ -34,6 +34,13 @@ MIN_EIG = 1e-3
 N_FRAMES = 8
 
 
+# HBM-side bytes of one lk_track_kernel<7> launch on this workload (2000 points), from separate rocprofv3 --pmc
+# FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_fetch.txt, r01_pmc_write.txt; KB x 1024).  The kernel's loads
+# are narrow (2- and 8-byte gathers), a pattern for which the guide gives no gfx950 FETCH_SIZE correction, so the
+# raw value is reported; it is far below the algorithmic bytes because the patches are served from L2 / MALL.
+LK7_PMC_TRAFFIC_BYTES = int((17876.6 + 142.2) * 1024)
+
+
 def lk_algorithmic_bytes(win, point_levels, iterations):
     """per point-level (w+1)^2 * (1 + 4) B of template patch, plus (w+1)^2 B of
     search-image window per Gauss-Newton iteration."""
@@ -236,7 +243,7 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": None,
+                "traffic": LK7_PMC_TRAFFIC_BYTES if n == 2000 else None,
                 "avg_launch_ms": round(lk_ms, 5),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "point_levels_per_launch": float(cnt_pair[1]),
