@@ -1,0 +1,25 @@
+import sys, time, numpy as np
+sys.path.insert(0, '/root/repo')
+from visual_odometry_amd import synthetic
+from visual_odometry_amd.frontend import FrontEnd
+from visual_odometry_amd import SequenceTracker
+H, W, seed, n, win, lvl = synthetic.CONFIGS["kitti"]
+fr = synthetic.sequence(H, W, seed, 8)
+fe = FrontEnd(0)
+c = fe.goodFeaturesToTrack(fr[0], n, 0.01, 7)
+pts = synthetic.pad_points(c, n, H, W, seed).T.copy()       # (2,N) as the reference passes them
+for _ in range(5): fe.track_keypoints(pts, fr[0], fr[1])
+t0 = time.perf_counter(); K = 100
+for i in range(K): fe.track_keypoints(pts, fr[i % 7], fr[i % 7 + 1])
+dt = (time.perf_counter() - t0) / K
+print("track_keypoints, numpy in / numpy out (2 image uploads, pyramids, LK, 3 downloads): %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
+trk = SequenceTracker(H, W, frontend=fe); trk.reset(fr[0])
+for i in range(5): trk.track(fr[i % 7 + 1], pts)
+t0 = time.perf_counter()
+for i in range(K): trk.track(fr[i % 8], pts)
+dt = (time.perf_counter() - t0) / K
+print("SequenceTracker.track, numpy in / numpy out (1 image upload): %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
+t0 = time.perf_counter()
+for i in range(K): fe.goodFeaturesToTrack(fr[i % 8], n, 0.01, 7)
+dt = (time.perf_counter() - t0) / K
+print("goodFeaturesToTrack, numpy in / numpy out: %.1f us/call" % (dt * 1e6))
