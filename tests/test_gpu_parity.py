@@ -381,3 +381,31 @@ def test_sequence_tracker_matches_per_call_path(fe):
     trk.close()
     with pytest.raises(Exception):
         SequenceTracker(H, W, frontend=fe).track(frames[0], land)
+
+
+# ------------------------------------------------------------------ BASELINE.json full-size configurations
+@pytest.mark.parametrize("cfg,md", [("malaga", 10), ("stress", 10)])
+def test_full_size_config_front_end_frame(fe, cfg, md):
+    """configs[2] (Malaga-shaped detection + tracking) and configs[4] (3840x2160, 20k points, 31x31, 5 levels)
+    at full size: detection identical to the oracle, forward-backward tracking bit-identical, and the
+    size-independent properties (sorted scores, minDistance respected, FB-consistent survivors)."""
+    H, W, seed, n, win, lvl = synthetic.CONFIGS[cfg]
+    a, b = synthetic.sequence(H, W, seed, 2)
+    got = fe.goodFeaturesToTrack(a, n, 0.01, md)
+    ref = oracle.goodFeaturesToTrack(a, n, 0.01, md, nthreads=16)
+    assert np.array_equal(got, ref)
+    xy = got.reshape(-1, 2)
+    sc = fe.corner_score(a)[xy[:, 1].astype(int), xy[:, 0].astype(int)]
+    assert (np.diff(sc) <= 0).all()                                   # strongest first
+    from scipy.spatial import cKDTree
+    assert len(cKDTree(xy).query_pairs(md - 1e-6)) == 0               # no two corners closer than minDistance
+    pts = synthetic.pad_points(got, n, H, W, seed).T.copy()
+    t1, s1, e1 = fe.track_keypoints(pts, a, b, win, lvl)
+    t0, s0, e0 = oracle.track_keypoints(pts, a, b, win, lvl, nthreads=16)
+    assert np.array_equal(s1, s0) and np.array_equal(t1, t0) and np.array_equal(e1, e0)
+    assert s1.mean() > 0.8
+    # survivors are forward-backward consistent by construction: tracking them back lands within 1 px
+    keep = s1 == 1
+    back, sb, _ = fe.calcOpticalFlowPyrLK(b, a, t1.T[keep].reshape(-1, 1, 2).astype(np.float32), None, win, lvl, (3, 30, 0.01), 0, 1e-3)
+    d = np.linalg.norm(back.reshape(-1, 2) - pts.T[keep], axis=1)
+    assert (d[sb.ravel() == 1] < 1.0).all()
