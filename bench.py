@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the feature front end's LK frame on MI355X (BASELINE.json configs[1]).
 
-One step = one "LK frame"  on a synthetic KITTI-shaped pair: Gaussian pyramids +
-Scharr planes of BOTH 1241x376 frames, forward LK of 2000 keypoints (21x21 window, 4 levels,
-criteria (30, 0.01), minEigThreshold 1e-3), backward LK from every forward result and the
-forward-backward check -- exactly what ContinuousVO._track_keypoints asks of cv2 per call
-(reference continuous.py:131-164).  Inputs (8 frames, point sets) are resident in HBM before the
+One "LK frame"  = a synthetic KITTI-shaped pair: Gaussian pyramids + Scharr planes
+of BOTH 1241x376 frames, forward LK of 2000 keypoints (21x21 window, 4 levels, criteria (30, 0.01),
+minEigThreshold 1e-3), backward LK from every forward result and the forward-backward check --
+exactly what ContinuousVO._track_keypoints asks of cv2 per call (reference continuous.py:131-164).
+One step = --batch independent LK frames (default 16) in one pyramid launch set + one LK launch.  Inputs (8 frames, point sets) are resident in HBM before the
 timed region; every step goes through the C ABI (libvofe.so).  N > 1: each rank tracks its own
 independent sequence (seed 100 + rank) -- replicas only, no collective on the data path.
 
@@ -34,11 +34,12 @@ MIN_EIG = 1e-3
 N_FRAMES = 8
 
 
-# HBM-side bytes of one lk_track_kernel<7> launch on this workload (2000 points), from separate rocprofv3 --pmc
-# FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_fetch.txt, r01_pmc_write.txt; KB x 1024).  The kernel's loads
-# are narrow (2- and 8-byte gathers), a pattern for which the guide gives no gfx950 FETCH_SIZE correction, so the
-# raw value is reported; it is far below the algorithmic bytes because the patches are served from L2 / MALL.
-LK7_PMC_TRAFFIC_BYTES = int((17876.6 + 142.2) * 1024)
+# HBM-side bytes of one lk_track_kernel<7> launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# over this very command (profiles/r01_pmc_bench_fetch.txt, r01_pmc_bench_write.txt; KB x 1024), keyed by
+# (pairs per launch, points per pair).  The kernel's loads are narrow (2- and 8-byte gathers), a pattern for
+# which the guide gives no gfx950 FETCH_SIZE correction, so the raw value is reported; it is well below the
+# algorithmic bytes because the patches are served from L2 / MALL.
+LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((363008.4 + 3247.8) * 1024), (1, 2000): int((18073.2 + 142.3) * 1024)}
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
@@ -51,11 +52,13 @@ def lk_algorithmic_bytes(win, point_levels, iterations):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=2000)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent frame pairs in flight per GPU (one ctx + HIP stream each); 1 = strictly serial")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="independent frame pairs per step: one pyramid launch set + one LK launch for all of them")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="steps in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -79,62 +82,81 @@ def main():
     fe = FrontEnd(local_rank)
     L = fe.L
     dev = fe.device
+    n, B = args.points, max(1, args.batch)
+    NP = N_FRAMES - 1                                       # frame pairs of the synthetic sequence
 
     # ---- inputs, resident in HBM ------------------------------------------------------------
     seed = replicas.sequence_seed(rank, world)
     frames = synthetic.sequence(H, W, seed=seed, n_frames=N_FRAMES)
     d_frames = torch.from_numpy(np.stack(frames)).to(dev)
     pts_host = []
-    for t in range(N_FRAMES - 1):
-        c = fe.goodFeaturesToTrack(d_frames[t], args.points, 0.01, 7)
-        pts_host.append(synthetic.pad_points(c, args.points, H, W, seed + t))
+    for t in range(NP):
+        c = fe.goodFeaturesToTrack(d_frames[t], n, 0.01, 7)
+        pts_host.append(synthetic.pad_points(c, n, H, W, seed + t))
     d_pts = [torch.from_numpy(p).to(dev) for p in pts_host]
-    n = args.points
     img_stride = H * W
+    # A step tracks B independent frame pairs (configs[1]: the pairs do not depend on each other).  Phase f
+    # of the input holds pairs (f + k) % NP, k < B, as [B previous frames | B next frames] with the point
+    # sets concatenated and an image index per point.
+    phases = []
+    for f in range(NP):
+        pairs = [(f + k) % NP for k in range(B)]
+        imgs = torch.cat([d_frames[pairs], d_frames[[q + 1 for q in pairs]]]).contiguous()
+        phases.append((imgs, torch.cat([d_pts[q] for q in pairs]).contiguous(), pairs))
+    d_idx = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(n).contiguous()
+    NB = n * B
     d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 
-    # S workers, each a ctx bound to its own HIP stream with its own pyramid object and outputs.  Frame
-    # pairs are independent (configs[1]), so pair i goes to worker i % S; inside a worker everything is
-    # in stream order.  S = 1 is the strictly serial schedule.
     class Worker:
-        def __init__(self, stream):
-            self.stream = stream
+        """A ctx bound to its own HIP stream with its own pyramid object (2*slots images) and outputs."""
+        def __init__(self, stream, pairs):
+            self.stream, self.pairs = stream, pairs
             with torch.cuda.stream(stream):
                 self.fe = FrontEnd(local_rank)
-                self.pyr = Pyramid(self.fe, 2, H, W, WIN, MAX_LEVEL, True)
-                self.nxt = torch.empty((n, 2), dtype=torch.float32, device=dev)
-                self.st = torch.empty(n, dtype=torch.uint8, device=dev)
-                self.err = torch.empty(n, dtype=torch.float32, device=dev)
+                self.pyr = Pyramid(self.fe, 2 * pairs, H, W, WIN, MAX_LEVEL, True)
+                self.nxt = torch.empty((n * pairs, 2), dtype=torch.float32, device=dev)
+                self.st = torch.empty(n * pairs, dtype=torch.uint8, device=dev)
+                self.err = torch.empty(n * pairs, dtype=torch.float32, device=dev)
 
-        def step(self, t, ev=None):
-            # reference-call-equivalent: both pyramids are rebuilt for every pair
-            f = self.fe
-            _lib.check(L.vofe_pyramid_build(f.ctx, self.pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
+        def step(self, f, ev=None):
+            # reference-call-equivalent: both pyramids of every pair are rebuilt (continuous.py:145-151)
+            imgs, pts, _ = phases[f]
+            c = self.fe.ctx
+            _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 2 * B, imgs.data_ptr(), W, img_stride))
             if ev is not None:
                 ev[0].record(self.stream)
-            _lib.check(L.vofe_track_fb(f.ctx, self.pyr._h, 0, self.pyr._h, 1, d_pts[t].data_ptr(), None,
-                                       self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, B, pts.data_ptr(), d_idx.data_ptr(),
+                                       self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), NB,
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
             if ev is not None:
                 ev[1].record(self.stream)
 
+        def step_one(self, t):
+            # one pair, strictly serial (latency figure)
+            c = self.fe.ctx
+            _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, 1, d_pts[t].data_ptr(), None,
+                                       self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
+                                       CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
+
         def step_cached(self, t):
             # frame-level schedule (SequenceTracker, SURVEY 8f): the previous frame's pyramid is still in its
             # slot, only the new frame's is built.  At the wrap of the short synthetic sequence frame 0 is rebuilt.
-            f = self.fe
+            c = self.fe.ctx
             if t == 0:
-                _lib.check(L.vofe_pyramid_build(f.ctx, self.pyr._h, 0, 1, d_frames[0].data_ptr(), W, 0))
-            _lib.check(L.vofe_pyramid_build(f.ctx, self.pyr._h, (t + 1) & 1, 1, d_frames[t + 1].data_ptr(), W, 0))
-            _lib.check(L.vofe_track_fb(f.ctx, self.pyr._h, t & 1, self.pyr._h, (t + 1) & 1, d_pts[t].data_ptr(), None,
+                _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 1, d_frames[0].data_ptr(), W, 0))
+            _lib.check(L.vofe_pyramid_build(c, self.pyr._h, (t + 1) & 1, 1, d_frames[t + 1].data_ptr(), W, 0))
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, t & 1, self.pyr._h, (t + 1) & 1, d_pts[t].data_ptr(), None,
                                        self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
 
     torch.cuda.synchronize()
-    workers = [Worker(torch.cuda.Stream(device=dev)) for _ in range(max(1, args.streams))]
+    workers = [Worker(torch.cuda.Stream(device=dev), B) for _ in range(max(1, args.streams))]
     S = len(workers)
+    w0 = workers[0]
 
     def step(i, ev=None):
-        workers[i % S].step(i % (N_FRAMES - 1), ev)
+        workers[i % S].step(i % NP, ev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,22 +166,22 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # tracked keypoints per frame pair (status == 1 after the forward-backward check), untimed
+    # tracked keypoints per phase (status == 1 after the forward-backward check), untimed
     tracked = []
-    for t in range(N_FRAMES - 1):
-        workers[0].step(t)
-        workers[0].stream.synchronize()
-        tracked.append(int(workers[0].st.sum().item()))
-    # work counters of the LK launches (point-levels, Gauss-Newton iterations): one untimed pass over the
-    # pairs, because the counting atomics would slow the timed launches
-    _lib.check(L.vofe_lk_set_counters(workers[0].fe.ctx, d_cnt.data_ptr()))
-    for t in range(N_FRAMES - 1):
-        workers[0].step(t)
+    for f in range(NP):
+        w0.step(f)
+        w0.stream.synchronize()
+        tracked.append(int(w0.st.sum().item()))
+    # work counters of the LK launch (point-levels, Gauss-Newton iterations): one untimed pass over the
+    # phases, because the counting atomics would slow the timed launches
+    _lib.check(L.vofe_lk_set_counters(w0.fe.ctx, d_cnt.data_ptr()))
+    for f in range(NP):
+        w0.step(f)
     torch.cuda.synchronize()
-    _lib.check(L.vofe_lk_set_counters(workers[0].fe.ctx, None))
-    cnt_pair = d_cnt.cpu().numpy().astype(np.float64) / (N_FRAMES - 1)
-    # HIP events around every EV_EVERY-th LK launch of the timed region (each record costs host time)
-    EV_EVERY = 8
+    _lib.check(L.vofe_lk_set_counters(w0.fe.ctx, None))
+    cnt_launch = d_cnt.cpu().numpy().astype(np.float64) / NP
+    # HIP events (on the worker's own stream) around every EV_EVERY-th LK launch of the timed region
+    EV_EVERY = 4
     events = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for i in range(0, args.steps, EV_EVERY)}
 
@@ -170,47 +192,40 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # the same K steps strictly serial on one stream (latency-oriented figure, reported beside value)
-    serial_ms = None
-    if S > 1:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            workers[0].step(i % (N_FRAMES - 1))
-        torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
-
-    # frame-level schedule with the cached pyramid: every worker walks the sequence in order
+    # ---- figures reported beside `value` (this rank only, untimed for the metric) ------------------
+    reps = 200
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(reps):
+        w0.step_one(i % NP)
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t1) / reps * 1e3
     t3 = time.perf_counter()
-    for i in range(args.steps):
-        workers[i % S].step_cached((i // S) % (N_FRAMES - 1))
+    for i in range(reps):
+        w0.step_cached(i % NP)
     torch.cuda.synchronize()
-    cached_fps = args.steps / (time.perf_counter() - t3)
-
-    # corner detection on the same geometry (one call per frame in the reference, continuous.py:380-385);
-    # not part of `value`, reported beside it.  Device-resident image in, corners copied back to the host.
+    cached_ms = (time.perf_counter() - t3) / reps * 1e3
+    # corner detection on the same geometry (one call per frame in the reference, continuous.py:380-385).
+    # Device-resident image in, corners copied back to the host.
     gftt_calls = 100
-    torch.cuda.synchronize()
     t2 = time.perf_counter()
     for i in range(gftt_calls):
-        fe.goodFeaturesToTrack(d_frames[i % N_FRAMES], args.points, 0.01, 7)
+        fe.goodFeaturesToTrack(d_frames[i % N_FRAMES], n, 0.01, 7)
     torch.cuda.synchronize()
     gftt_us = (time.perf_counter() - t2) / gftt_calls * 1e6
 
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
-    tracked_per_step = [tracked[i % (N_FRAMES - 1)] for i in range(args.steps)]
-    tsum = float(sum(tracked_per_step))
-
+    tsum = float(sum(tracked[i % NP] for i in range(args.steps)))
     elapsed, (tsum,) = replicas.fold(dist, dev, elapsed, [tsum])
 
-    frames_total = args.steps * world
+    frames_total = args.steps * B * world
     fps = frames_total / elapsed
 
     out = None
     if rank == 0:
-        alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_pair[1]), float(cnt_pair[2]))
+        alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_launch[1]), float(cnt_launch[2]))
         achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        kernel = "lk_track_kernel<7> (fwd + bwd + FB check of %d pairs x %d points in one launch)" % (B, n)
         out = {
             "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",
             "value": round(fps, 2),
@@ -227,29 +242,31 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
                                    "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
                                    "reference-call-equivalent (both pyramids rebuilt per pair)" % n,
-                       "frames_per_step": 1, "points": n, "sequences": world, "streams_per_gpu": S,
-                       "parallelism": "replicas only (one sequence per GPU); %d independent pairs in flight per GPU" % S},
-            "single_stream_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
-            "cached_pyramid_frames_per_s": round(cached_fps, 1),
-            "cached_pyramid_note": "same LK work, one pyramid built per new frame (SequenceTracker schedule); this rank only",
+                       "frames_per_step": B, "points": n, "sequences": world, "streams_per_gpu": S,
+                       "parallelism": "replicas only (one sequence per GPU); a step is %d independent frame pairs in one "
+                                      "launch set, %d steps in flight per GPU" % (B, S)},
+            "single_pair_serial_ms": round(serial_ms, 4),
+            "single_pair_serial_cached_pyramid_ms": round(cached_ms, 4),
+            "cached_pyramid_note": "same LK work, one pyramid built per new frame (SequenceTracker schedule); serial, this rank",
             "gftt_us_per_call": round(gftt_us, 1),
             "gftt_config": "goodFeaturesToTrack(1241x376, maxCorners=%d, qualityLevel=0.01, minDistance=7), serial calls" % n,
             "tracked_keypoints_per_s": round(tsum / elapsed, 1),
             "attempted_points_per_s": round(frames_total * n / elapsed, 1),
             "roofline": {
-                "kernel": "lk_track_kernel<7> (fwd + bwd + FB check in one launch)",
+                "kernel": kernel,
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": LK7_PMC_TRAFFIC_BYTES if n == 2000 else None,
+                "traffic": LK7_PMC_TRAFFIC_BYTES.get((B, n)),
                 "avg_launch_ms": round(lk_ms, 5),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
-                "point_levels_per_launch": float(cnt_pair[1]),
-                "gn_iterations_per_launch": float(cnt_pair[2]),
-                "note": "gather + VALU + LDS bound (SURVEY 8d): patches are L2/LDS resident, so the HBM fraction is "
-                        "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2",
+                "point_levels_per_launch": float(cnt_launch[1]),
+                "gn_iterations_per_launch": float(cnt_launch[2]),
+                "note": "VALU-issue bound, not HBM (DESIGN.md 4/5): patches are L2/MALL resident, so the HBM fraction is "
+                        "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2; traffic = PMC FETCH_SIZE + "
+                        "WRITE_SIZE of this launch shape (profiles/r01_pmc_bench_*.txt)",
             },
         }
         if not args.no_cpu:
