@@ -135,7 +135,7 @@ __device__ __forceinline__ unsigned gload_u8(const void* p) { return *((const VO
 // (rx0, ry0).  One task = one row x 8 entries = 9 consecutive bytes of J (an unaligned 8-byte load
 // plus one byte); a lane runs up to ST_BATCH tasks per batch with all loads issued before the first
 // LDS write, so a staging pass costs one memory latency, not one per task.
-constexpr int ST_BATCH = 4;
+constexpr int ST_BATCH = 2;
 struct StageRegs { uint2 v[ST_BATCH]; unsigned nb[ST_BATCH]; };
 
 __device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_h,
