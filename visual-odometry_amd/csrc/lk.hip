@@ -117,6 +117,15 @@ __device__ __forceinline__ uint2 gload_u64(const void* p) {
 }
 __device__ __forceinline__ unsigned gload_u16(const void* p) { return *((const VOFE_GLOBAL u16_unaligned*)p); }
 __device__ __forceinline__ unsigned gload_u8(const void* p) { return *((const VOFE_GLOBAL uint8_t*)p); }
+// Wave-uniform 64-bit base (SGPR pair) + unsigned 32-bit lane offset: the global_load saddr form, so the
+// per-lane address arithmetic stays 32-bit (no v_mad_i64 / 64-bit adds per load).
+typedef const VOFE_GLOBAL uint8_t* gbase_t;
+__device__ __forceinline__ uint2 gload_u64(gbase_t b, unsigned off) {
+    const u32x2 v = *((const VOFE_GLOBAL u32x2_unaligned*)(b + off));
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned gload_u16(gbase_t b, unsigned off) { return *((const VOFE_GLOBAL u16_unaligned*)(b + off)); }
+__device__ __forceinline__ unsigned gload_u8(gbase_t b, unsigned off) { return *(b + off); }
 
 // Diagnostic build only (-DLK_STAMPS): s_memtime deltas per phase, written to counters[8 + 8*block + k]
 // for the first 256 blocks.  Never enabled in the shipped library.
@@ -138,9 +147,11 @@ __device__ __forceinline__ unsigned gload_u8(const void* p) { return *((const VO
 constexpr int ST_BATCH = 2;
 struct StageRegs { uint2 v[ST_BATCH]; unsigned nb[ST_BATCH]; };
 
-__device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_h,
-                                           int rx0, int ry0, int segs, int inv_segs, int tasks, int t0, int lane) {
+__device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_w,
+                                           int win_h, int rx0, int ry0, int segs, int inv_segs, int tasks, int t0, int lane) {
     const int ymin = -win_h, ymax = B.h + win_h - 1;
+    // uniform base = first byte any task can touch (row ymin, column rx0); rx0 >= -win_w - 4 lies in the padding
+    const gbase_t base = (gbase_t)(J0 + (long long)ymin * B.pitch + rx0);
 #pragma unroll
     for (int k = 0; k < ST_BATCH; ++k) {
         const int t = t0 + k * 64 + lane;
@@ -150,9 +161,9 @@ __device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restri
         s.nb[k] = 0u;
         if (t < tasks) {
             const int gy = min(max(ry0 + row, ymin), ymax);
-            const uint8_t* p = J0 + (long long)gy * B.pitch + (rx0 + seg * 8);
-            s.v[k] = gload_u64(p);
-            s.nb[k] = gload_u8(p + 8);
+            const unsigned off = (unsigned)((gy - ymin) * B.pitch + seg * 8);
+            s.v[k] = gload_u64(base, off);
+            s.nb[k] = gload_u8(base, off + 8u);
         }
     }
 }
@@ -178,11 +189,11 @@ __device__ __forceinline__ void stage_write(const StageRegs& s, unsigned* lds, i
     }
 }
 // remaining batches (windows wider than ~31 px) and re-staging after the walk left the region
-__device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_h,
+__device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restrict__ J0, const VofeLevel& B, int win_w, int win_h,
                                            int rx0, int ry0, int segs, int inv_segs, int tasks, int t_begin, int lane) {
     for (int t0 = t_begin; t0 < tasks; t0 += 64 * ST_BATCH) {
         StageRegs s;
-        stage_load(s, J0, B, win_h, rx0, ry0, segs, inv_segs, tasks, t0, lane);
+        stage_load(s, J0, B, win_w, win_h, rx0, ry0, segs, inv_segs, tasks, t0, lane);
         stage_write(s, lds, segs, inv_segs, tasks, t0, lane);
     }
 }
@@ -235,17 +246,19 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
-            const long long base = (long long)slotA * A.slot_stride + (long long)(ipy + y0) * A.pitch + ipx + x;
-            const uint8_t* Ib = A.I + base;
-            const int* Db = A.D + base;
+            // uniform bases at the window's top-left pixel; lane offsets are (y0 + r) * pitch + x >= 0
+            const long long base = (long long)slotA * A.slot_stride + (long long)ipy * A.pitch + ipx;
+            const gbase_t Ib = (gbase_t)(A.I + base);
+            const gbase_t Db = (gbase_t)(A.D + base);
+            const unsigned off0 = (unsigned)(y0 * A.pitch + x);
             unsigned pI[R + 1];
             unsigned pX[R + 1], pY[R + 1];     // (Ix[x] | Ix[x+1] << 16), (Iy[x] | Iy[x+1] << 16)
-            if (staged) stage_load(pre, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+            if (staged) stage_load(pre, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
 #pragma unroll
             for (int r = 0; r <= R; ++r) {
-                const long long off = (long long)min(r, ny) * A.pitch;
-                const unsigned two = gload_u16(Ib + off);
-                const uint2 dd = gload_u64(Db + off);
+                const unsigned off = off0 + (unsigned)(min(r, ny) * A.pitch);
+                const unsigned two = gload_u16(Ib, off);
+                const uint2 dd = gload_u64(Db, off * 4u);
                 pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
                 pX[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
                 pY[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
@@ -284,7 +297,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         if (staged) {
             __syncthreads();
             stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
-            stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
+            stage_rest(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
             __syncthreads();
         }
         STAMP_END(2);
@@ -297,7 +310,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                stage_rest(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
@@ -347,7 +360,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_rest(lds, J0, B, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                stage_rest(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
