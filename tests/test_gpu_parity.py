@@ -101,6 +101,18 @@ def test_lk_matches_oracle(fe, h, w, seed, win, lvl, npts):
     assert st.sum() > 0.5 * npts
 
 
+def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
+    """21x21 windows normally run the compile-time specialisation; the run-time-geometry kernel must agree."""
+    monkeypatch.setenv("VOFE_LK", "generic")
+    a, b = _seq(240, 320, 12)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 400, 0.01, 7), 400, 240, 320, 12)
+    exact, _, st = _lk_compare(fe, a, b, pts, (21, 21), 3)
+    assert exact and st.sum() > 200
+    t1 = fe.track_keypoints(pts.T, a, b)
+    t0 = oracle.track_keypoints(pts.T, a, b, nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
+
+
 def test_lk_flags_initial_flow_and_min_eig(fe):
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 300, 0.01, 7), 300, 240, 320, 12)

@@ -198,17 +198,26 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
     }
 }
 
-template <int R>
+constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
+
+// WC != 0: compile-time square window WC x WC with R * groups == WC (every active lane owns exactly R rows;
+// idle lanes sit on row 0 with ny == 0), so window geometry, the LDS row stride and all row offsets fold to
+// constants (LDS reads take immediate offsets).  WC == 0: everything at run time, ragged last group allowed.
+template <int R, int WC>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* lds, int lane, int x, int y0,
                                        int ny, unsigned& n_lv, unsigned& n_it, unsigned long long* st_acc) {
     STAMP_DECL
     (void)st_acc;
-    const int w = a.win_w, h = a.win_h;
+    const int w = WC ? WC : a.win_w, h = WC ? WC : a.win_h;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
-    const int rs = a.rs, segs = a.segs, inv_segs = a.inv_segs, tasks = a.rh * a.segs;
+    constexpr int SEGS_C = (WC + 1 + 2 * LK_MARGIN + 7) / 8;
+    const int segs = WC ? SEGS_C : a.segs, rs = 8 * segs;
+    const int inv_segs = WC ? (1 << 20) / SEGS_C + 1 : a.inv_segs;
+    const int tasks = (WC ? WC + 1 + 2 * LK_MARGIN : a.rh) * segs;
+#define LK_ROW(r) (WC ? (r) : min((r), ny))
     for (int level = top; level >= 0; --level) {
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
@@ -256,7 +265,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (staged) stage_load(pre, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
 #pragma unroll
             for (int r = 0; r <= R; ++r) {
-                const unsigned off = off0 + (unsigned)(min(r, ny) * A.pitch);
+                const unsigned off = off0 + (unsigned)(LK_ROW(r) * A.pitch);
                 const unsigned two = gload_u16(Ib, off);
                 const uint2 dd = gload_u64(Db, off * 4u);
                 pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
@@ -264,12 +273,15 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 pY[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
             }
             int a11 = 0, a12 = 0, a22 = 0;
+            // rows a lane does not own must contribute Ix = Iy = 0.  With the regular mapping (WC) a lane owns
+            // all R rows or none, so zero weights do it: (0 + 8192) >> 14 == 0.
+            const unsigned dw0 = (WC && ny == 0) ? 0u : q.w0, dw1 = (WC && ny == 0) ? 0u : q.w1;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
-                int ix = sdot2(pX[k], q.w0, sdot2(pX[k + 1], q.w1, 8192)) >> 14;
-                int iy = sdot2(pY[k], q.w0, sdot2(pY[k + 1], q.w1, 8192)) >> 14;
-                if (k >= ny) { ix = 0; iy = 0; }
+                int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
+                int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                if (!WC && k >= ny) { ix = 0; iy = 0; }
                 Ival[k] = iv;
                 Dval[k] = (ix & 0xffff) | (iy << 16);
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
@@ -320,7 +332,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
 #pragma unroll
-            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rs];
+            for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -344,7 +356,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             // decides all but the borderline cases, which take the exact path
             const float d2 = dx * dx + dy * dy;
             bool conv = d2 < a.eps2_lo;
-            if (!conv && !(d2 > a.eps2_hi)) conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
+            if (__any(!conv && !(d2 > a.eps2_hi)))          // ballot: keeps the f64 sequence out of the common path
+                conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
             if (conv) break;
             // |(double)(float)(dx+pdx)| < 0.01  <=>  |f32 value| <= 0.01f (the largest float below 0.01)
             if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
@@ -353,7 +366,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             }
             pdx = dx; pdy = dy;
         }
-        if (status && level == 0 && !(flags & 8)) {
+        if (status && level == 0 && !(flags & 8) && !(flags & LK_NO_ERR)) {
             const float ex = outx - hx, ey = outy - hy;
             const int inx = floor_i(ex), iny = floor_i(ey);
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) { status = 0; continue; }
@@ -368,32 +381,35 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
 #pragma unroll
-            for (int r = 0; r <= R; ++r) P[r] = lp[min(r, ny) * rs];
+            for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
             int se = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
                 const int diff = jv - Ival[k];
-                se += (k < ny) ? abs(diff) : 0;
+                se += (WC || k < ny) ? abs(diff) : 0;
             }
+            if (WC && ny == 0) se = 0;
             err = wave_sum_to_float(se) / (float)(32 * w * h);
         }
         __syncthreads();     // all LDS reads of this level done before the next level restages
     }
 }
 
-template <int R>
-// 145 VGPRs -> 3 waves per SIMD.  Capping the allocation for 4 or 5 waves (amdgpu_waves_per_eu) was
-// measured: the spills cost more than the occupancy gives (52.8 -> 65.9 / 79.9 us, throughput down too).
+#undef LK_ROW
+// Register budget decides the occupancy (R = 7: 109 VGPRs -> 4 waves per SIMD).  Capping the allocation
+// further (amdgpu_waves_per_eu) was measured: the spills cost more than the occupancy gives.
+template <int R, int WC>
 __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     extern __shared__ unsigned lds[];
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
-    const int g = lane / a.win_w;
-    const int x = lane - g * a.win_w;
-    const bool active = g < a.groups;
-    const int y0 = min(g * a.rows_per_group, a.win_h);
-    const int ny = active ? min(a.rows_per_group, a.win_h - y0) : 0;
+    const int ww = WC ? WC : a.win_w, wh = WC ? WC : a.win_h;
+    const int g = lane / ww;
+    const int x = lane - g * ww;
+    const bool active = g < (WC ? WC / R : a.groups);
+    const int y0 = WC ? (active ? g * R : 0) : min(g * a.rows_per_group, wh);
+    const int ny = WC ? (active ? R : 0) : (active ? min(a.rows_per_group, wh - y0) : 0);
 
     const float2 p = a.prev_pts[i];
     const int idx = a.img_idx ? a.img_idx[i] : 0;
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        lk_one<R>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? 0 : a.flags, lds, lane, x, y0, ny, n_lv, n_it, st_acc);
+        lk_one<R, WC>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, lds, lane, x, y0, ny, n_lv, n_it, st_acc);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
     }
@@ -437,9 +453,9 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     }
 }
 
-template <int R>
+template <int R, int WC = 0>
 void launch_r(const LKArgs& a, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(lk_track_kernel<R>, dim3(a.n), dim3(64), lds_bytes, st, a);
+    hipLaunchKernelGGL((lk_track_kernel<R, WC>), dim3(a.n), dim3(64), lds_bytes, st, a);
 }
 
 }  // namespace
@@ -480,7 +496,9 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     const size_t lds_bytes = (size_t)a.rs * a.rh * 4;
     const int R = a.rows_per_group;
     hipStream_t st = ctx->stream;
-    if (R <= 2) launch_r<2>(a, lds_bytes, st);
+    const char* force = getenv("VOFE_LK");                       // "generic" skips the 21x21 specialisation (tests)
+    if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
+    else if (R <= 2) launch_r<2>(a, lds_bytes, st);
     else if (R <= 3) launch_r<3>(a, lds_bytes, st);
     else if (R <= 4) launch_r<4>(a, lds_bytes, st);
     else if (R <= 7) launch_r<7>(a, lds_bytes, st);
