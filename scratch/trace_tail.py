@@ -7,7 +7,7 @@ calls = []
 for r in rows:
     if 'corner_score' in r['Kernel_Name']: calls.append([])
     if calls: calls[-1].append(r)
-for idx in (4,):
+for idx in (5,):
     if idx >= len(calls): continue
     c = calls[idx]; t0 = int(c[0]['Start_Timestamp'])
     print('--- call', idx, 'total', (int(c[-1]['End_Timestamp']) - t0) / 1e3, 'us')

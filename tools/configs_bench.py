@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] (bench.py covers configs[1]).
+
+Front-end frame = what one process_frame asks of the feature front end: forward-backward
+tracking of the frame's points + goodFeaturesToTrack on the new frame.  Reported device-resident
+(images and points already in HBM, results left there except the corner list) in the
+reference-call-equivalent mode (both pyramids rebuilt) and the cached mode (one pyramid per new
+frame), and host-to-host through the Python mirror.  Prints one JSON object per config.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from visual_odometry_amd import synthetic, _lib, SequenceTracker   # noqa: E402
+from visual_odometry_amd.frontend import FrontEnd, Pyramid         # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def front_end_frame(fe, cfg, md, reps):
+    H, W, seed, n, win, lvl = synthetic.CONFIGS[cfg]
+    L = fe.L
+    fr = synthetic.sequence(H, W, seed, 3)
+    d = torch.from_numpy(np.stack(fr)).cuda()
+    c = fe.goodFeaturesToTrack(d[0], n, 0.01, md)
+    pts = synthetic.pad_points(c, n, H, W, seed)
+    dp = torch.from_numpy(pts).cuda()
+    dn = torch.empty_like(dp); ds = torch.empty(n, dtype=torch.uint8, device="cuda"); de = torch.empty(n, device="cuda")
+    pyr = Pyramid(fe, 2, H, W, win, lvl, True)
+
+    def track(slot_a, slot_b):
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, slot_a, pyr._h, slot_b, dp.data_ptr(), None, dn.data_ptr(), ds.data_ptr(),
+                                   de.data_ptr(), n, 3, 30, 0.01, 1e-3, 1.0))
+
+    def ref_equiv():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2, d.data_ptr(), W, H * W))
+        track(0, 1)
+        fe.goodFeaturesToTrack(d[1], n, 0.01, md)
+
+    def cached():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 1, 1, d[1].data_ptr(), W, 0))
+        track(0, 1)
+        fe.goodFeaturesToTrack(d[1], n, 0.01, md)
+
+    def lk_only():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2, d.data_ptr(), W, H * W))
+        track(0, 1)
+
+    t_ref, t_cached, t_lk = timed(ref_equiv, reps), timed(cached, reps), timed(lk_only, reps)
+    tracked = int(ds.sum().item())
+    pyr.free()
+    trk = SequenceTracker(H, W, winSize=win, maxLevel=lvl, frontend=fe)
+    trk.reset(fr[0])
+    k = [0]
+
+    def host():
+        k[0] += 1
+        trk.track(fr[k[0] % 3], pts.T)
+        trk.detect(n, 0.01, md)
+    t_host = timed(host, max(3, reps // 4))
+    trk.close()
+    return {"config": cfg, "frame": "%dx%d, %d points, win %dx%d, %d levels, GFTT maxCorners %d minDistance %d" %
+            (W, H, n, win[0], win[1], lvl + 1, n, md),
+            "front_end_frame_us_reference_call_equivalent": round(t_ref * 1e6, 1),
+            "front_end_frame_us_cached_pyramid": round(t_cached * 1e6, 1),
+            "lk_frame_us": round(t_lk * 1e6, 1),
+            "front_end_frame_us_host_numpy_in_out_cached": round(t_host * 1e6, 1),
+            "frames_per_s_cached": round(1 / t_cached, 1), "tracked_of_attempted": [tracked, n]}
+
+
+def sequences_64(fe, reps):
+    H, W, seed, n, win, lvl = synthetic.CONFIGS["kitti"]
+    L = fe.L
+    B = 64
+    base = [synthetic.sequence(H, W, 100 + s, 2) for s in range(4)]
+    pts = [synthetic.pad_points(fe.goodFeaturesToTrack(b[0], n, 0.01, 7), n, H, W, 100 + s) for s, b in enumerate(base)]
+    d = torch.from_numpy(np.stack([base[s % 4][0] for s in range(B)] + [base[s % 4][1] for s in range(B)])).cuda()
+    dp = torch.from_numpy(np.concatenate([pts[s % 4] for s in range(B)])).cuda()
+    idx = torch.arange(B, dtype=torch.int32).repeat_interleave(n).cuda()
+    N = n * B
+    dn = torch.empty_like(dp); ds = torch.empty(N, dtype=torch.uint8, device="cuda"); de = torch.empty(N, device="cuda")
+    pyr = Pyramid(fe, 2 * B, H, W, win, lvl, True)
+
+    def step():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2 * B, d.data_ptr(), W, H * W))
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, dp.data_ptr(), idx.data_ptr(), dn.data_ptr(), ds.data_ptr(),
+                                   de.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0))
+    t = timed(step, reps)
+    out, cnt = None, None
+
+    def gftt():
+        nonlocal out, cnt
+        out, cnt = fe.goodFeaturesToTrack_batch(d[:B], 1000, 0.01, 10)
+    tg = timed(gftt, max(2, reps // 2))
+    pyr.free()
+    return {"config": "64 sequences (one launch set per frame index)", "lk_frames_per_s": round(B / t, 1),
+            "us_per_64_frames": round(t * 1e6, 1), "gftt_batch64_us": round(tg * 1e6, 1),
+            "gftt_us_per_image": round(tg * 1e6 / B, 2), "tracked_fraction": round(float(ds.float().mean()), 4)}
+
+
+def main():
+    fe = FrontEnd(0)
+    res = [front_end_frame(fe, "malaga", 10, 100), front_end_frame(fe, "stress", 10, 20), sequences_64(fe, 8)]
+    fe.close()
+    for r in res:
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

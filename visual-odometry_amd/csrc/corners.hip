@@ -379,7 +379,8 @@ __global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__
                 make_uint4(cnt[4 * i][c], cnt[4 * i + 1][c], cnt[4 * i + 2][c], cnt[4 * i + 3][c]);
     for (int k = 0; k < N_SEG; ++k) {
         unsigned long long want = base ? ((unsigned long long)base << k) : (unsigned long long)n;
-        if (k == N_SEG - 1 || want > n) want = n;
+        // a prefix that is already a sizeable part of the list is not worth a possible second pass
+        if (k == N_SEG - 1 || want > n || (unsigned long long)n <= 6ull * base) want = n;
         const unsigned tk = (unsigned)want;
         if (tk == 0) { if (t == 0) hdr[blockIdx.x].seg_end[k] = 0; continue; }
         if (!(bstart[0] < tk && e0 >= tk)) continue;          // the boundary bucket is not among this thread's
