@@ -115,6 +115,15 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
               int block_size, int aperture, int harris, double k, float* d_corners_xy,
               int capacity, int* h_n_out);
 
+/* Same call with the corner list delivered to host memory as cv2.goodFeaturesToTrack delivers it
+ * (reference continuous.py:380-385 consumes it as a numpy array): h_corners_xy (host, capacity (x,y)
+ * pairs) receives min(*h_n_out, capacity) corners together with the count, in the call's single
+ * synchronisation.  d_corners_xy (device, capacity pairs) is still filled. */
+int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
+                   int max_corners, double quality, double min_distance, const uint8_t* d_mask,
+                   int block_size, int aperture, int harris, double k, float* d_corners_xy,
+                   float* h_corners_xy, int capacity, int* h_n_out);
+
 /* Batched variant: `batch` images of identical geometry; image b writes its corners to
  * d_corners_xy + b*capacity*2 and its count to h_n_out[b].  No mask. */
 int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,

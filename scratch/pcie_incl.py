@@ -12,7 +12,7 @@ for _ in range(5): fe.track_keypoints(pts, fr[0], fr[1])
 t0 = time.perf_counter(); K = 100
 for i in range(K): fe.track_keypoints(pts, fr[i % 7], fr[i % 7 + 1])
 dt = (time.perf_counter() - t0) / K
-print("track_keypoints, numpy in / numpy out (2 image uploads, pyramids, LK, 3 downloads): %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
+print("track_keypoints, numpy in / numpy out (2 image uploads, pyramids, LK, 1 packed download): %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
 trk = SequenceTracker(H, W, frontend=fe); trk.reset(fr[0])
 for i in range(5): trk.track(fr[i % 7 + 1], pts)
 t0 = time.perf_counter()

@@ -290,6 +290,23 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
                           d_corners_xy, capacity, h_n_out);
 }
 
+int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
+                   int max_corners, double quality, double min_distance, const uint8_t* d_mask,
+                   int block_size, int aperture, int harris, double k, float* d_corners_xy,
+                   float* h_corners_xy, int capacity, int* h_n_out) {
+    if (!h_n_out || !h_corners_xy) { vofe_set_error("vofe_gftt_host: h_n_out / h_corners_xy is NULL"); return VOFE_E_ARG; }
+    *h_n_out = 0;
+    if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0) {
+        vofe_set_error("vofe_gftt_host: need qualityLevel > 0, minDistance >= 0, maxCorners >= 0");
+        return VOFE_E_ARG;
+    }
+    int rc = corner_args("vofe_gftt_host", ctx, d_img, height, width, pitch, block_size, aperture);
+    if (rc) return rc;
+    if (capacity <= 0 || !d_corners_xy) { vofe_set_error("vofe_gftt_host: bad output buffer"); return VOFE_E_ARG; }
+    return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
+                          d_corners_xy, capacity, h_n_out, h_corners_xy);
+}
+
 int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
                     int pitch, size_t img_stride, int max_corners, double quality,
                     double min_distance, int block_size, int aperture, int harris, double k,

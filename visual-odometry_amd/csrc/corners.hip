@@ -14,6 +14,7 @@
 // accepted; ranks are (score, linear index) compared directly, so no global sort is needed before
 // selection and only the accepted corners are sorted.
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "vofe_internal.h"
@@ -795,7 +796,7 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out) {
+                   int* h_n_out, float* h_corners_xy) {
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
@@ -805,7 +806,17 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
     int rc = ensure_ws(ctx, tot);
     if (rc) return rc;
-    rc = ensure_pinned(ctx, (sizeof(GfttHdr) / 4) * (size_t)batch);
+    // pinned staging: headers, then (single image, host output requested) the corner list itself, so that
+    // corners and count arrive with the one synchronisation of the call
+    const size_t hdr_ints = (sizeof(GfttHdr) / 4) * (size_t)batch;
+    size_t stage_floats = 0;
+    if (h_corners_xy && batch == 1) {
+        long long m = capacity;
+        if (max_corners > 0 && max_corners < m) m = max_corners;
+        stage_floats = (size_t)std::max<long long>(m, 0) * 2;
+        if (stage_floats > 2 * (size_t)RANK_MAX) stage_floats = 0;       // unbounded lists are fetched after the count is known
+    }
+    rc = ensure_pinned(ctx, hdr_ints + stage_floats);
     if (rc) return rc;
     uint8_t* base = static_cast<uint8_t*>(ctx->ws);
     GfttHdr* hdr = reinterpret_cast<GfttHdr*>(base);
@@ -881,6 +892,9 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             hipLaunchKernelGGL(emit_ranked, dim3(gi, batch), dim3(256), 0, st, keys, hdr, px, rank, px, w, d_corners_xy,
                                capacity, max_out);
         }
+        if (stage_floats && use_rank)
+            VOFE_HIP(hipMemcpyAsync(reinterpret_cast<int*>(ctx->h_pinned) + hdr_ints, d_corners_xy, stage_floats * sizeof(float),
+                                    hipMemcpyDeviceToHost, st));
         VOFE_HIP(hipMemcpyAsync(hh, hdr, sizeof(GfttHdr) * batch, hipMemcpyDeviceToHost, st));
         VOFE_HIP(hipStreamSynchronize(st));
         bool converged = true, enough = true;
@@ -916,6 +930,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const size_t lds = (size_t)SORT_CH * 8;
     if (use_rank && nmax <= RANK_MAX) {
         // already sorted and emitted by the speculative rank sort
+        if (h_corners_xy && stage_floats) {
+            memcpy(h_corners_xy, reinterpret_cast<int*>(ctx->h_pinned) + hdr_ints, (size_t)h_n_out[0] * 2 * sizeof(float));
+            return VOFE_OK;
+        }
     } else if (chunks == 1) {
         unsigned len = 64;
         while (len < nmax) len <<= 1;
@@ -940,5 +958,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "gftt launch");
+    if (h_corners_xy && batch == 1) {
+        const size_t nb = (size_t)std::min(h_n_out[0], max_out) * 2 * sizeof(float);
+        VOFE_HIP(hipMemcpyAsync(h_corners_xy, d_corners_xy, nb, hipMemcpyDeviceToHost, st));
+        VOFE_HIP(hipStreamSynchronize(st));
+    }
     return VOFE_OK;
 }

@@ -62,7 +62,7 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out);
+                   int* h_n_out, float* h_corners_xy = nullptr);
 
 // ---- device helpers shared by kernels ------------------------------------------------------
 __device__ __forceinline__ int vofe_reflect101(int p, int n) {

@@ -137,6 +137,16 @@ class FrontEnd:
             self._pyr_cache[key] = p
         return p
 
+    def _packed_outputs(self, n):
+        """One device allocation for (next (n,2) f32 | err (n,) f32 | status (n,) u8): one D2H, one sync."""
+        buf = torch.empty(n * 13, dtype=torch.uint8, device=self.device)
+        return buf, buf[: n * 8].view(torch.float32).view(n, 2), buf[n * 8: n * 12].view(torch.float32), buf[n * 12:]
+
+    @staticmethod
+    def _unpack_outputs(buf, n):
+        h = buf.cpu().numpy()
+        return (h[: n * 8].view(np.float32).reshape(n, 2), h[n * 12:], h[n * 8: n * 12].view(np.float32))
+
     @staticmethod
     def _points(prevPts):
         p = np.asarray(prevPts)
@@ -157,20 +167,17 @@ class FrontEnd:
         pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
         pyr.build(torch.stack([a, b]), 0)
         d_prev = torch.from_numpy(p).to(self.device)
+        buf, d_next, d_err, d_st = self._packed_outputs(n)
         if flags & OPTFLOW_USE_INITIAL_FLOW:
             q = self._points(nextPts)
             if q.shape != p.shape:
                 raise error(-1, "nextPts must match prevPts with OPTFLOW_USE_INITIAL_FLOW")
-            d_next = torch.from_numpy(q).to(self.device)
-        else:
-            d_next = torch.empty_like(d_prev)
-        d_st = torch.empty(n, dtype=torch.uint8, device=self.device)
-        d_err = torch.empty(n, dtype=torch.float32, device=self.device)
+            d_next.copy_(torch.from_numpy(q))
         _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, d_next.data_ptr(),
                                         d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
                                         float(criteria[2]), int(flags), float(minEigThreshold)))
-        return (d_next.cpu().numpy().reshape(-1, 1, 2), d_st.cpu().numpy().reshape(-1, 1),
-                d_err.cpu().numpy().reshape(-1, 1))
+        nxt, st, err = self._unpack_outputs(buf, n)
+        return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
 
     def track_keypoints(self, prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,
                         criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3, fb_thresh=1.0):
@@ -186,13 +193,12 @@ class FrontEnd:
         pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
         pyr.build(torch.stack([a, b]), 0)
         d_prev = torch.from_numpy(p).to(self.device)
-        d_next = torch.empty_like(d_prev)
-        d_st = torch.empty(n, dtype=torch.uint8, device=self.device)
-        d_err = torch.empty(n, dtype=torch.float32, device=self.device)
+        buf, d_next, d_err, d_st = self._packed_outputs(n)
         _lib.check(self.L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, d_next.data_ptr(),
                                         d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
                                         float(criteria[2]), float(minEigThreshold), float(fb_thresh)))
-        return d_next.cpu().numpy().T, d_st.cpu().numpy(), d_err.cpu().numpy()
+        nxt, st, err = self._unpack_outputs(buf, n)
+        return nxt.T, st, err
 
     def corner_score(self, image, useHarrisDetector=False, k=0.04, blockSize=3, ksize=3):
         a = self.to_device(image)
@@ -216,13 +222,14 @@ class FrontEnd:
         n = C.c_int(0)
         if a.stride(1) != 1:
             a = a.contiguous()
-        _lib.check(self.L.vofe_gftt(self.ctx, a.data_ptr(), h, w, a.stride(0), int(maxCorners), float(qualityLevel),
-                                    float(minDistance), d_mask.data_ptr() if d_mask is not None else None,
-                                    int(blockSize), int(gradientSize), int(bool(useHarrisDetector)), float(k),
-                                    out.data_ptr(), cap, C.byref(n)))
+        host = np.empty((max(cap, 1), 2), dtype=np.float32)      # corners and count arrive in one synchronisation
+        _lib.check(self.L.vofe_gftt_host(self.ctx, a.data_ptr(), h, w, a.stride(0), int(maxCorners), float(qualityLevel),
+                                         float(minDistance), d_mask.data_ptr() if d_mask is not None else None,
+                                         int(blockSize), int(gradientSize), int(bool(useHarrisDetector)), float(k),
+                                         out.data_ptr(), host.ctypes.data, max(cap, 1), C.byref(n)))
         if n.value == 0:
             return None
-        return out[: n.value].cpu().numpy().reshape(-1, 1, 2)
+        return host[: n.value].copy().reshape(-1, 1, 2)
 
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):

@@ -63,13 +63,11 @@ class SequenceTracker:
         if n:
             fe = self.fe
             d_prev = torch.from_numpy(np.concatenate(flat, 0)).to(fe.device)
-            d_next = torch.empty_like(d_prev)
-            d_st = torch.empty(n, dtype=torch.uint8, device=fe.device)
-            d_err = torch.empty(n, dtype=torch.float32, device=fe.device)
+            buf, d_next, d_err, d_st = fe._packed_outputs(n)
             _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, d_prev.data_ptr(), None,
                                           d_next.data_ptr(), d_st.data_ptr(), d_err.data_ptr(), n, self.criteria[0],
                                           self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
-            nxt, st, err = d_next.cpu().numpy(), d_st.cpu().numpy(), d_err.cpu().numpy()
+            nxt, st, err = fe._unpack_outputs(buf, n)
         out, o = [], 0
         for p in sets:
             if p.size == 0:
