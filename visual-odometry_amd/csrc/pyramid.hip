@@ -48,25 +48,46 @@ __global__ __launch_bounds__(256) void pad_copy_level0(const uint8_t* __restrict
 // One thread = 8 consecutive output pixels of one padded output row.
 __device__ __forceinline__ unsigned byte_of(const unsigned* w, int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
 
+// one reflected-coordinate output pixel (borders, ragged last group)
+__device__ __forceinline__ unsigned pyr_down_px(const uint8_t* __restrict__ sp, int spitch, int rx, int ry) {
+    int acc = 128;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int wk = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
+        const uint8_t* r = sp + (long long)(2 * ry - 2 + k) * spitch + 2 * rx;
+        acc += wk * ((int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0]);
+    }
+    return (unsigned)(acc >> 8);
+}
+
+// Rows of the REFLECT_101 border band are copies of interior rows, so every row runs the vector path at
+// the reflected row index.  Column groups outside the image (and the ragged last group) are filled after a
+// block barrier: outside pixels copy the reflected pixel of the same output row, which a thread of the
+// same block has just written (one block spans the row whenever `exchange` is set); only the few
+// in-image pixels of a ragged last group are computed one by one.
 __global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, int slot0, int win_w,
                                                    int win_h, int gx0, int ngx) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngx) return;
+    const bool live = g < ngx;
     const int Y = (int)blockIdx.y - win_h;
+    const int ry = vofe_reflect101(Y, Dl.h);
     const int X0 = (g + gx0) * 8;
     const long long so = (long long)(slot0 + (int)blockIdx.z) * S.slot_stride;
     const long long dofs = (long long)(slot0 + (int)blockIdx.z) * Dl.slot_stride;
     const uint8_t* sp = S.I + so;
-    uint8_t* d = Dl.I + dofs + (long long)Y * Dl.pitch + X0;
+    uint8_t* drow = Dl.I + dofs + (long long)Y * Dl.pitch;
+    const bool full = live && X0 >= 0 && X0 + 8 <= Dl.w;
+    // every reflected column of the bands lands in a complete group of this block's row
+    const bool exchange = gridDim.x == 1 && Dl.w >= 8 - gx0 * 8 && Dl.w >= win_w + 16;
     unsigned out[8];
-    if (X0 >= 0 && X0 + 8 <= Dl.w && Y >= 0 && Y < Dl.h) {
+    if (full) {
         int acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 128;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int wk = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
-            const uint8_t* r = sp + (long long)(2 * Y - 2 + k) * S.pitch + 2 * X0 - 4;
+            const uint8_t* r = sp + (long long)(2 * ry - 2 + k) * S.pitch + 2 * X0 - 4;
             unsigned wv[6];
             U4 a = *reinterpret_cast<const U4*>(r);
             U2 b = *reinterpret_cast<const U2*>(r + 16);
@@ -81,24 +102,32 @@ __global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, in
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = (unsigned)(acc[j] >> 8);
-    } else {
-        const int ry = vofe_reflect101(Y, Dl.h);
+    } else if (live && !exchange) {
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) out[j] = pyr_down_px(sp, S.pitch, vofe_reflect101(X0 + j, Dl.w), ry);
+    }
+    if (live && (full || !exchange)) {
+        uint2 o;
+        o.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+        o.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+        *reinterpret_cast<uint2*>(drow + X0) = o;
+    }
+    if (!exchange) return;                          // uniform
+    __threadfence_block();
+    __syncthreads();
+    if (live && !full) {
+        const int wfull = Dl.w & ~7;
 #pragma unroll 1
         for (int j = 0; j < 8; ++j) {
-            const int rx = vofe_reflect101(X0 + j, Dl.w);
-            int acc = 128;
-            for (int k = 0; k < 5; ++k) {
-                const int wk = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
-                const uint8_t* r = sp + (long long)(2 * ry - 2 + k) * S.pitch + 2 * rx;
-                acc += wk * ((int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0]);
-            }
-            out[j] = (unsigned)(acc >> 8);
+            const int x = X0 + j;
+            const int rx = vofe_reflect101(x, Dl.w);
+            out[j] = (x != rx && rx < wfull) ? (unsigned)drow[rx] : pyr_down_px(sp, S.pitch, rx, ry);
         }
+        uint2 o;
+        o.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+        o.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+        *reinterpret_cast<uint2*>(drow + X0) = o;
     }
-    uint2 o;
-    o.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-    o.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-    *reinterpret_cast<uint2*>(d) = o;
 }
 
 // ---------------------------------------------------------------------------------------------
