@@ -421,3 +421,38 @@ def test_full_size_config_front_end_frame(fe, cfg, md):
     back, sb, _ = fe.calcOpticalFlowPyrLK(b, a, t1.T[keep].reshape(-1, 1, 2).astype(np.float32), None, win, lvl, (3, 30, 0.01), 0, 1e-3)
     d = np.linalg.norm(back.reshape(-1, 2) - pts.T[keep], axis=1)
     assert (d[sb.ravel() == 1] < 1.0).all()
+
+
+def test_ragged_batch_of_sequences_in_one_launch(fe):
+    """configs[3] batching: B pairs in one pyramid object, points of all pairs in ONE launch with a per-point
+    image index (ragged: different counts per pair, one pair with none) == the per-pair results."""
+    import ctypes as C
+    import torch
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import Pyramid
+    H, W, B = 120, 200, 4
+    pairs = [_seq(H, W, 60 + s, 2) for s in range(B)]
+    counts = [90, 0, 37, 150]
+    rng = np.random.default_rng(1)
+    pts = [(rng.random((c, 2)) * [W - 1, H - 1]).astype(np.float32) for c in counts]
+    imgs = torch.from_numpy(np.stack([p[0] for p in pairs] + [p[1] for p in pairs])).cuda()
+    pyr = Pyramid(fe, 2 * B, H, W, (21, 21), 3, True)
+    pyr.build(imgs, 0)
+    allp = torch.from_numpy(np.concatenate(pts)).cuda()
+    idx = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), counts)).cuda()
+    n = int(sum(counts))
+    nxt = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    st = torch.empty(n, dtype=torch.uint8, device="cuda")
+    err = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), idx.data_ptr(), nxt.data_ptr(), st.data_ptr(),
+                                  err.data_ptr(), n, 3, 30, 0.01, 1e-3, 1.0))
+    nxt, st, err = nxt.cpu().numpy(), st.cpu().numpy(), err.cpu().numpy()
+    o = 0
+    for s in range(B):
+        if counts[s] == 0:
+            continue
+        t0, s0, e0 = oracle.track_keypoints(pts[s].T, pairs[s][0], pairs[s][1], nthreads=4)
+        k = counts[s]
+        assert np.array_equal(nxt[o:o + k].T, t0) and np.array_equal(st[o:o + k], s0) and np.array_equal(err[o:o + k], e0)
+        o += k
+    pyr.free()
