@@ -113,6 +113,38 @@ def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
 
 
+def test_lk_two_keypoints_per_wavefront_kernel(fe, monkeypatch):
+    """Launches of >= 12288 points with 21x21 windows take the kernel that packs two keypoints into one
+    wavefront; forced here on small inputs: odd counts, wild points, flags, extreme contrast, FB twin."""
+    monkeypatch.setenv("VOFE_LK", "x2")
+    a, b = _seq(240, 320, 12)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 12)
+    for lvl in (3, 0):
+        exact, _, st = _lk_compare(fe, a, b, pts, (21, 21), lvl)
+        assert exact and st.sum() > 200
+    init = (pts + np.float32([1.0, 0.5])).astype(np.float32)
+    assert _lk_compare(fe, a, b, pts, (21, 21), 3, flags=4, init=init)[0]
+    assert _lk_compare(fe, a, b, pts, (21, 21), 3, flags=8, min_eig=1e-3)[0]
+    assert _lk_compare(fe, a, b, pts[:1], (21, 21), 2)[0]
+    t1 = fe.track_keypoints(pts.T, a, b)
+    t0 = oracle.track_keypoints(pts.T, a, b, nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
+    wild = np.float32([[-30, 5], [5, -30], [400, 50], [50, 400], [-11.5, -11.5], [319.9, 239.9], [0, 0],
+                       [80, 60], [np.nan, 3], [1e12, 1e12], [-1e20, 4], [np.inf, 0], [100, 100]])
+    flat = np.full_like(a, 77)
+    for (x, y) in ((a, b), (flat, flat), (a, flat)):
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(x, y, wild, None, (21, 21), 2)
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(x, y, wild, None, (21, 21), 2)
+        assert np.array_equal(s0, s1) and np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True)
+    rng = np.random.default_rng(17)
+    hc = np.kron((rng.random((60, 80)) > 0.5).astype(np.uint8) * 255, np.ones((4, 4), np.uint8))
+    hd = np.roll(hc, (1, 2), axis=(0, 1))
+    p2 = (rng.random((301, 2)) * [319, 239]).astype(np.float32)
+    n0, s0, e0 = oracle.calcOpticalFlowPyrLK(hc, hd, p2, None, (21, 21), 2, (3, 30, 0.01), 0, 1e-4, nthreads=8)
+    n1, s1, e1 = fe.calcOpticalFlowPyrLK(hc, hd, p2, None, (21, 21), 2, (3, 30, 0.01), 0, 1e-4)
+    assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
+
+
 def test_lk_flags_initial_flow_and_min_eig(fe):
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 300, 0.01, 7), 300, 240, 320, 12)

@@ -198,6 +198,7 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
     }
 }
 
+constexpr int LK_X2_MIN_POINTS = 12288;    // below this a launch does not fill the GPU and latency matters more
 constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
 
 // WC != 0: compile-time square window WC x WC with R * groups == WC (every active lane owns exactly R rows;
@@ -453,6 +454,317 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two keypoints per wavefront (21x21 windows, large launches).  The single-point kernel spends more
+// than half of its VALU instructions on work that is uniform across the wave (bilinear weights, the
+// 2x2 solve, convergence tests, bounds, addressing); a wave64 instruction costs 4 SIMD cycles whether
+// it serves one keypoint or two.  Here each half of the wave (32 lanes) owns one keypoint; a lane
+// owns two 7-row strips of the window (strip s = lane32 + 32 q, column s % 21, rows 7 (s / 21) .. +6,
+// 63 strips in all), each half has its own LDS search region, and everything that was wave-uniform
+// becomes half-uniform lane data.  The halves diverge freely (different level outcomes, iteration
+// counts, restaging): the compiler's EXEC masking keeps that correct, and an exhausted half only idles.
+// Arithmetic is identical to lk_one, so results stay bit-identical.
+namespace x2 {
+constexpr int W = 21, R = 7, NS = 2;
+constexpr int RW = W + 1 + 2 * LK_MARGIN, SEGS = (RW + 7) / 8, RS = 8 * SEGS, RH = W + 1 + 2 * LK_MARGIN;
+constexpr int TASKS = RH * SEGS, TB = (TASKS + 31) / 32, REGION = RH * RS;
+static_assert(SEGS == 4, "task -> (row, seg) uses shifts");
+
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// exact sum over the 32 lanes of a half, result in every lane of the half
+__device__ __forceinline__ int half_sum(int v, int partner_addr) {
+    v = row_sum16(v);
+    return v + __builtin_amdgcn_ds_bpermute(partner_addr, v);
+}
+__device__ __forceinline__ float half_sum_to_float(int v, int partner_addr) {
+    const int lo = half_sum(v & 0xffff, partner_addr);
+    const int hi = half_sum(v >> 16, partner_addr);
+    return (float)((long long)hi * 65536 + (long long)lo);
+}
+
+struct Stage { uint2 v[TB]; unsigned nb[TB]; };
+// Addresses are a wave-uniform base (the plane's first reachable byte: row -W, column -PADX of slot 0) plus an
+// unsigned 32-bit lane offset that includes the half's slot, so loads keep the saddr form although the two
+// halves read different images.  The host takes this kernel only when a whole plane set fits 32-bit offsets.
+constexpr int PADX = W + 8;
+__device__ __forceinline__ gbase_t plane_base(const uint8_t* I0, int pitch) { return (gbase_t)(I0 - (long long)W * pitch - PADX); }
+__device__ __forceinline__ void stage_load(Stage& s, gbase_t Jb, unsigned slot_off, const VofeLevel& B, int rx0, int ry0, int l32) {
+    const int ymin = -W, ymax = B.h + W - 1;
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+        const int t = k * 32 + l32;
+        const int row = t >> 2, seg = t & 3;
+        s.v[k] = make_uint2(0u, 0u);
+        s.nb[k] = 0u;
+        if (t < TASKS) {
+            const int gy = min(max(ry0 + row, ymin), ymax);
+            const unsigned off = slot_off + (unsigned)((gy + W) * B.pitch + (rx0 + PADX + seg * 8));
+            s.v[k] = gload_u64(Jb, off);
+            s.nb[k] = gload_u8(Jb, off + 8u);
+        }
+    }
+}
+__device__ __forceinline__ void stage_write(const Stage& s, unsigned* region, int l32) {
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+        const int t = k * 32 + l32;
+        if (t < TASKS) {
+            const unsigned lo = s.v[k].x, hi = s.v[k].y, nb = s.nb[k];
+            uint4 a, b;
+            a.x = __builtin_amdgcn_perm(0u, lo, 0x0c010c00u);
+            a.y = __builtin_amdgcn_perm(0u, lo, 0x0c020c01u);
+            a.z = __builtin_amdgcn_perm(0u, lo, 0x0c030c02u);
+            a.w = __builtin_amdgcn_perm(hi, lo, 0x0c040c03u);
+            b.x = __builtin_amdgcn_perm(0u, hi, 0x0c010c00u);
+            b.y = __builtin_amdgcn_perm(0u, hi, 0x0c020c01u);
+            b.z = __builtin_amdgcn_perm(0u, hi, 0x0c030c02u);
+            b.w = __builtin_amdgcn_perm(nb, hi, 0x0c040c03u);
+            uint4* d = reinterpret_cast<uint4*>(region + t * 8);
+            d[0] = a; d[1] = b;
+        }
+    }
+}
+__device__ __forceinline__ void restage(unsigned* region, gbase_t Jb, unsigned slot_off, const VofeLevel& B, int rx0, int ry0, int l32) {
+    Stage s;
+    lds_order();
+    stage_load(s, Jb, slot_off, B, rx0, ry0, l32);
+    stage_write(s, region, l32);
+    lds_order();
+}
+
+__device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
+                                       int slotA, int slotB, float px, float py, float& outx, float& outy,
+                                       int& status, float& err, int flags, unsigned* region, int l32, int partner_addr,
+                                       const int (&sx)[NS], const int (&sy0)[NS], const bool (&sok)[NS],
+                                       unsigned& n_lv, unsigned& n_it) {
+    constexpr int w = W, h = W;
+    const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
+    const int top = a.n_levels - 1;
+    for (int level = top; level >= 0; --level) {
+        const VofeLevel A = LA[level];
+        const VofeLevel B = LB[level];
+        const float sc = 1.0f / (float)(1 << level);
+        float ppx = px * sc, ppy = py * sc;
+        float npx, npy;
+        if (level == top) {
+            if (flags & 4) { npx = outx * sc; npy = outy * sc; }
+            else { npx = ppx; npy = ppy; }
+        } else { npx = outx * 2.f; npy = outy * 2.f; }
+        outx = npx; outy = npy;
+        ppx -= hx; ppy -= hy;
+        const int ipx = floor_i(ppx), ipy = floor_i(ppy);
+        if (ipx < -w || ipx >= A.w || ipy < -h || ipy >= A.h) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        ++n_lv;
+        const gbase_t Jb = plane_base(B.I, B.pitch);
+        const unsigned jslot = (unsigned)slotB * (unsigned)B.slot_stride;
+        bool staged = false;
+        int rx0 = 0, ry0 = 0;
+        Stage pre;
+        {
+            const int fx = floor_i(npx - hx), fy = floor_i(npy - hy);
+            if (!(fx < -w || fx >= B.w || fy < -h || fy >= B.h)) {
+                rx0 = fx - LK_MARGIN; ry0 = fy - LK_MARGIN;
+                staged = true;
+            }
+        }
+        int Ival[NS][R], Dval[NS][R];
+        float fA11, fA12, fA22;
+        {
+            const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
+            const gbase_t Ib = plane_base(A.I, A.pitch);
+            const gbase_t Db = (gbase_t)((const uint8_t*)A.D - 4 * ((long long)W * A.pitch + PADX));
+            const unsigned tbase = (unsigned)slotA * (unsigned)A.slot_stride + (unsigned)((ipy + W) * A.pitch + ipx + PADX);
+            if (staged) stage_load(pre, Jb, jslot, B, rx0, ry0, l32);
+            int a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const unsigned off0 = tbase + (unsigned)(sy0[s] * A.pitch + sx[s]);
+                unsigned pI[R + 1], pX[R + 1], pY[R + 1];
+#pragma unroll
+                for (int r = 0; r <= R; ++r) {
+                    const unsigned off = off0 + (unsigned)(r * A.pitch);
+                    const unsigned two = gload_u16(Ib, off);
+                    const uint2 dd = gload_u64(Db, off * 4u);
+                    pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
+                    pX[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
+                    pY[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
+                }
+                // a strip that does not exist (the 64th) contributes Ix = Iy = 0 through zero weights
+                const unsigned dw0 = sok[s] ? q.w0 : 0u, dw1 = sok[s] ? q.w1 : 0u;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
+                    const int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
+                    const int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                    Ival[s][k] = iv;
+                    Dval[s][k] = (ix & 0xffff) | (iy << 16);
+                    a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                }
+            }
+            if (partials_fit(a11, a12, a22)) {
+                fA11 = (float)half_sum(a11, partner_addr); fA12 = (float)half_sum(a12, partner_addr);
+                fA22 = (float)half_sum(a22, partner_addr);
+            } else {
+                fA11 = half_sum_to_float(a11, partner_addr); fA12 = half_sum_to_float(a12, partner_addr);
+                fA22 = half_sum_to_float(a22, partner_addr);
+            }
+        }
+        const float FLT_SCALE = 1.f / (float)(1 << 20);
+        const float A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
+        float Dd = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
+        if (flags & 8) err = minEig;
+        if (minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        Dd = 1.f / Dd;
+        npx -= hx; npy -= hy;
+        float pdx = 0.f, pdy = 0.f;
+        if (staged) {
+            lds_order();
+            stage_write(pre, region, l32);
+            lds_order();
+        }
+        for (int j = 0; j < a.max_count; ++j) {
+            const int inx = floor_i(npx), iny = floor_i(npy);
+            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                restage(region, Jb, jslot, B, rx0, ry0, l32);
+                staged = true;
+            }
+            ++n_it;
+            const Wts q = bilinear_weights(npx, npy, inx, iny);
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const unsigned* lp = region + (iny - ry0 + sy0[s]) * RS + (inx - rx0) + sx[s];
+                unsigned P[R + 1];
+#pragma unroll
+                for (int r = 0; r <= R; ++r) P[r] = lp[r * RS];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
+                    const int diff = jv - Ival[s][k];
+                    b1 += diff * (int)(short)Dval[s][k];
+                    b2 += diff * (Dval[s][k] >> 16);
+                }
+            }
+            float fb1, fb2;
+            if (partials_fit(b1, b2)) { fb1 = (float)half_sum(b1, partner_addr); fb2 = (float)half_sum(b2, partner_addr); }
+            else { fb1 = half_sum_to_float(b1, partner_addr); fb2 = half_sum_to_float(b2, partner_addr); }
+            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * Dd;
+            const float dy = (A12 * fb1 - A11 * fb2) * Dd;
+            npx += dx; npy += dy;
+            outx = npx + hx; outy = npy + hy;
+            const float d2 = dx * dx + dy * dy;
+            bool conv = d2 < a.eps2_lo;
+            if (!conv && !(d2 > a.eps2_hi)) conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
+            if (conv) break;
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0 && !(flags & 8) && !(flags & LK_NO_ERR)) {
+            const float ex = outx - hx, ey = outy - hy;
+            const int inx = floor_i(ex), iny = floor_i(ey);
+            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) { status = 0; continue; }
+            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                restage(region, Jb, jslot, B, rx0, ry0, l32);
+                staged = true;
+            }
+            const Wts q = bilinear_weights(ex, ey, inx, iny);
+            int se = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const unsigned* lp = region + (iny - ry0 + sy0[s]) * RS + (inx - rx0) + sx[s];
+                unsigned P[R + 1];
+#pragma unroll
+                for (int r = 0; r <= R; ++r) P[r] = lp[r * RS];
+                int ss = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
+                    ss += abs(jv - Ival[s][k]);
+                }
+                se += sok[s] ? ss : 0;
+            }
+            err = half_sum_to_float(se, partner_addr) / (float)(32 * w * h);
+        }
+        lds_order();
+    }
+}
+}  // namespace x2
+
+__global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
+    extern __shared__ unsigned lds[];
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    int i = (int)blockIdx.x * 2 + half;
+    const bool valid = i < a.n;
+    if (!valid) i = a.n - 1;                      // an odd tail: the spare half shadows the last point, writes nothing
+    unsigned* region = lds + half * x2::REGION;
+    const int partner_addr = (lane ^ 16) << 2;
+    int sx[x2::NS], sy0[x2::NS];
+    bool sok[x2::NS];
+#pragma unroll
+    for (int s = 0; s < x2::NS; ++s) {
+        const int seg = l32 + 32 * s;
+        sok[s] = seg < 3 * x2::W;
+        const int g = sok[s] ? seg / x2::W : 0;
+        sx[s] = sok[s] ? seg - g * x2::W : 0;
+        sy0[s] = g * x2::R;
+    }
+    const float2 p = a.prev_pts[i];
+    const int idx = a.img_idx ? a.img_idx[i] : 0;
+    float fx = 0.f, fy = 0.f;
+    if (a.flags & 4) { const float2 q = a.next_pts[i]; fx = q.x; fy = q.y; }
+    int st = 1;
+    float er = 0.f;
+    float bx = 0.f, by = 0.f;
+    const int ndir = a.fb ? 2 : 1;
+    unsigned n_lv = 0, n_it = 0;
+    for (int dir = 0; dir < ndir; ++dir) {
+        const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
+        const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
+        const int sa = (dir ? a.slot_b : a.slot_a) + idx, sb = (dir ? a.slot_a : a.slot_b) + idx;
+        float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
+        float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
+        int s = 1;
+        x2::lk_one(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0, sok,
+                   n_lv, n_it);
+        if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
+        else { bx = ox; by = oy; }
+    }
+    if (a.fb) {
+        const float dx = fabsf(p.x - bx), dy = fabsf(p.y - by);
+        float d = dx > dy ? dx : dy;
+        if (dx != dx || dy != dy) d = __builtin_nanf("");
+        st = st & (d < a.fb_thresh ? 1 : 0);
+    }
+    if (l32 == 0 && valid) {
+        a.next_pts[i] = make_float2(fx, fy);
+        a.status[i] = (uint8_t)st;
+        a.err[i] = er;
+        if (a.counters) {
+            atomicAdd(a.counters + 0, 1ull);
+            atomicAdd(a.counters + 1, (unsigned long long)n_lv);
+            atomicAdd(a.counters + 2, (unsigned long long)n_it);
+        }
+    }
+}
+
 template <int R, int WC = 0>
 void launch_r(const LKArgs& a, size_t lds_bytes, hipStream_t st) {
     hipLaunchKernelGGL((lk_track_kernel<R, WC>), dim3(a.n), dim3(64), lds_bytes, st, a);
@@ -497,7 +809,15 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     const int R = a.rows_per_group;
     hipStream_t st = ctx->stream;
     const char* force = getenv("VOFE_LK");                       // "generic" skips the 21x21 specialisation (tests)
-    if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
+    // large 21x21 launches saturate the vector ALUs: two keypoints per wavefront share the uniform work there;
+    // small launches are latency bound and keep one keypoint per wavefront ("x2" / "x1" force a kernel)
+    // (its 32-bit lane offsets must span every slot of a level's derivative plane)
+    const unsigned long long span_a = (unsigned long long)prev->slots * (unsigned long long)prev->lv[0].slot_stride * 4ull;
+    const unsigned long long span_b = (unsigned long long)next->slots * (unsigned long long)next->lv[0].slot_stride * 4ull;
+    const bool x2_ok = a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g') && span_a < 0xf0000000ull && span_b < 0xf0000000ull;
+    if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
+        hipLaunchKernelGGL(lk_track_kernel_x2, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+    else if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
     else if (R <= 2) launch_r<2>(a, lds_bytes, st);
     else if (R <= 3) launch_r<3>(a, lds_bytes, st);
     else if (R <= 4) launch_r<4>(a, lds_bytes, st);
