@@ -113,10 +113,11 @@ def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
 
 
-def test_lk_two_keypoints_per_wavefront_kernel(fe, monkeypatch):
-    """Launches of >= 12288 points with 21x21 windows take the kernel that packs two keypoints into one
-    wavefront; forced here on small inputs: odd counts, wild points, flags, extreme contrast, FB twin."""
-    monkeypatch.setenv("VOFE_LK", "x2")
+@pytest.mark.parametrize("ppw", ["x2", "x4"])
+def test_lk_several_keypoints_per_wavefront_kernel(fe, monkeypatch, ppw):
+    """Large 21x21 launches take the kernel that packs several keypoints into one wavefront; forced here on
+    small inputs: counts not divisible by the packing, wild points, flags, extreme contrast, FB twin."""
+    monkeypatch.setenv("VOFE_LK", ppw)
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 12)
     for lvl in (3, 0):

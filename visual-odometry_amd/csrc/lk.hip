@@ -465,35 +465,43 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
 // counts, restaging): the compiler's EXEC masking keeps that correct, and an exhausted half only idles.
 // Arithmetic is identical to lk_one, so results stay bit-identical.
 namespace x2 {
-constexpr int W = 21, R = 7, NS = 2;
+constexpr int W = 21, R = 7;
 constexpr int RW = W + 1 + 2 * LK_MARGIN, SEGS = (RW + 7) / 8, RS = 8 * SEGS, RH = W + 1 + 2 * LK_MARGIN;
-constexpr int TASKS = RH * SEGS, TB = (TASKS + 31) / 32, REGION = RH * RS;
+constexpr int TASKS = RH * SEGS, REGION = RH * RS;
 static_assert(SEGS == 4, "task -> (row, seg) uses shifts");
+// PPW keypoints per wavefront (2 or 4): a group of GL = 64 / PPW lanes owns one keypoint, a lane owns NS strips
+template <int PPW> struct Cfg {
+    static constexpr int GL = 64 / PPW, NS = (3 * W + GL - 1) / GL, TB = (TASKS + GL - 1) / GL;
+};
 
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// exact sum over the 32 lanes of a half, result in every lane of the half
+// exact sum over the lanes of a group (one or two DPP rows), result in every lane of the group
+template <int PPW>
 __device__ __forceinline__ int half_sum(int v, int partner_addr) {
     v = row_sum16(v);
-    return v + __builtin_amdgcn_ds_bpermute(partner_addr, v);
+    if (PPW == 2) v += __builtin_amdgcn_ds_bpermute(partner_addr, v);
+    return v;
 }
+template <int PPW>
 __device__ __forceinline__ float half_sum_to_float(int v, int partner_addr) {
-    const int lo = half_sum(v & 0xffff, partner_addr);
-    const int hi = half_sum(v >> 16, partner_addr);
+    const int lo = half_sum<PPW>(v & 0xffff, partner_addr);
+    const int hi = half_sum<PPW>(v >> 16, partner_addr);
     return (float)((long long)hi * 65536 + (long long)lo);
 }
 
-struct Stage { uint2 v[TB]; unsigned nb[TB]; };
+template <int PPW> struct Stage { uint2 v[Cfg<PPW>::TB]; unsigned nb[Cfg<PPW>::TB]; };
 // Addresses are a wave-uniform base (the plane's first reachable byte: row -W, column -PADX of slot 0) plus an
 // unsigned 32-bit lane offset that includes the half's slot, so loads keep the saddr form although the two
 // halves read different images.  The host takes this kernel only when a whole plane set fits 32-bit offsets.
 constexpr int PADX = W + 8;
 __device__ __forceinline__ gbase_t plane_base(const uint8_t* I0, int pitch) { return (gbase_t)(I0 - (long long)W * pitch - PADX); }
-__device__ __forceinline__ void stage_load(Stage& s, gbase_t Jb, unsigned slot_off, const VofeLevel& B, int rx0, int ry0, int l32) {
+template <int PPW>
+__device__ __forceinline__ void stage_load(Stage<PPW>& s, gbase_t Jb, unsigned slot_off, const VofeLevel& B, int rx0, int ry0, int l32) {
     const int ymin = -W, ymax = B.h + W - 1;
 #pragma unroll
-    for (int k = 0; k < TB; ++k) {
-        const int t = k * 32 + l32;
+    for (int k = 0; k < Cfg<PPW>::TB; ++k) {
+        const int t = k * Cfg<PPW>::GL + l32;
         const int row = t >> 2, seg = t & 3;
         s.v[k] = make_uint2(0u, 0u);
         s.nb[k] = 0u;
@@ -505,10 +513,11 @@ __device__ __forceinline__ void stage_load(Stage& s, gbase_t Jb, unsigned slot_o
         }
     }
 }
-__device__ __forceinline__ void stage_write(const Stage& s, unsigned* region, int l32) {
+template <int PPW>
+__device__ __forceinline__ void stage_write(const Stage<PPW>& s, unsigned* region, int l32) {
 #pragma unroll
-    for (int k = 0; k < TB; ++k) {
-        const int t = k * 32 + l32;
+    for (int k = 0; k < Cfg<PPW>::TB; ++k) {
+        const int t = k * Cfg<PPW>::GL + l32;
         if (t < TASKS) {
             const unsigned lo = s.v[k].x, hi = s.v[k].y, nb = s.nb[k];
             uint4 a, b;
@@ -525,19 +534,22 @@ __device__ __forceinline__ void stage_write(const Stage& s, unsigned* region, in
         }
     }
 }
+template <int PPW>
 __device__ __forceinline__ void restage(unsigned* region, gbase_t Jb, unsigned slot_off, const VofeLevel& B, int rx0, int ry0, int l32) {
-    Stage s;
+    Stage<PPW> s;
     lds_order();
-    stage_load(s, Jb, slot_off, B, rx0, ry0, l32);
-    stage_write(s, region, l32);
+    stage_load<PPW>(s, Jb, slot_off, B, rx0, ry0, l32);
+    stage_write<PPW>(s, region, l32);
     lds_order();
 }
 
+template <int PPW>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* region, int l32, int partner_addr,
-                                       const int (&sx)[NS], const int (&sy0)[NS], const bool (&sok)[NS],
-                                       unsigned& n_lv, unsigned& n_it) {
+                                       const int (&sx)[Cfg<PPW>::NS], const int (&sy0)[Cfg<PPW>::NS],
+                                       const bool (&sok)[Cfg<PPW>::NS], unsigned& n_lv, unsigned& n_it) {
+    constexpr int NS = Cfg<PPW>::NS;
     constexpr int w = W, h = W;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
@@ -563,7 +575,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         const unsigned jslot = (unsigned)slotB * (unsigned)B.slot_stride;
         bool staged = false;
         int rx0 = 0, ry0 = 0;
-        Stage pre;
+        Stage<PPW> pre;
         {
             const int fx = floor_i(npx - hx), fy = floor_i(npy - hy);
             if (!(fx < -w || fx >= B.w || fy < -h || fy >= B.h)) {
@@ -578,7 +590,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const gbase_t Ib = plane_base(A.I, A.pitch);
             const gbase_t Db = (gbase_t)((const uint8_t*)A.D - 4 * ((long long)W * A.pitch + PADX));
             const unsigned tbase = (unsigned)slotA * (unsigned)A.slot_stride + (unsigned)((ipy + W) * A.pitch + ipx + PADX);
-            if (staged) stage_load(pre, Jb, jslot, B, rx0, ry0, l32);
+            if (staged) stage_load<PPW>(pre, Jb, jslot, B, rx0, ry0, l32);
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -606,11 +618,11 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 }
             }
             if (partials_fit(a11, a12, a22)) {
-                fA11 = (float)half_sum(a11, partner_addr); fA12 = (float)half_sum(a12, partner_addr);
-                fA22 = (float)half_sum(a22, partner_addr);
+                fA11 = (float)half_sum<PPW>(a11, partner_addr); fA12 = (float)half_sum<PPW>(a12, partner_addr);
+                fA22 = (float)half_sum<PPW>(a22, partner_addr);
             } else {
-                fA11 = half_sum_to_float(a11, partner_addr); fA12 = half_sum_to_float(a12, partner_addr);
-                fA22 = half_sum_to_float(a22, partner_addr);
+                fA11 = half_sum_to_float<PPW>(a11, partner_addr); fA12 = half_sum_to_float<PPW>(a12, partner_addr);
+                fA22 = half_sum_to_float<PPW>(a22, partner_addr);
             }
         }
         const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -627,7 +639,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         float pdx = 0.f, pdy = 0.f;
         if (staged) {
             lds_order();
-            stage_write(pre, region, l32);
+            stage_write<PPW>(pre, region, l32);
             lds_order();
         }
         for (int j = 0; j < a.max_count; ++j) {
@@ -638,7 +650,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             }
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                restage(region, Jb, jslot, B, rx0, ry0, l32);
+                restage<PPW>(region, Jb, jslot, B, rx0, ry0, l32);
                 staged = true;
             }
             ++n_it;
@@ -659,8 +671,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 }
             }
             float fb1, fb2;
-            if (partials_fit(b1, b2)) { fb1 = (float)half_sum(b1, partner_addr); fb2 = (float)half_sum(b2, partner_addr); }
-            else { fb1 = half_sum_to_float(b1, partner_addr); fb2 = half_sum_to_float(b2, partner_addr); }
+            if (partials_fit(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
+            else { fb1 = half_sum_to_float<PPW>(b1, partner_addr); fb2 = half_sum_to_float<PPW>(b2, partner_addr); }
             fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * Dd;
             const float dy = (A12 * fb1 - A11 * fb2) * Dd;
@@ -682,7 +694,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) { status = 0; continue; }
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                restage(region, Jb, jslot, B, rx0, ry0, l32);
+                restage<PPW>(region, Jb, jslot, B, rx0, ry0, l32);
                 staged = true;
             }
             const Wts q = bilinear_weights(ex, ey, inx, iny);
@@ -701,26 +713,28 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 }
                 se += sok[s] ? ss : 0;
             }
-            err = half_sum_to_float(se, partner_addr) / (float)(32 * w * h);
+            err = half_sum_to_float<PPW>(se, partner_addr) / (float)(32 * w * h);
         }
         lds_order();
     }
 }
 }  // namespace x2
 
+template <int PPW>
 __global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
     extern __shared__ unsigned lds[];
-    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
-    int i = (int)blockIdx.x * 2 + half;
+    constexpr int GL = x2::Cfg<PPW>::GL, NS = x2::Cfg<PPW>::NS;
+    const int lane = threadIdx.x, l32 = lane & (GL - 1), half = lane / GL;
+    int i = (int)blockIdx.x * PPW + half;
     const bool valid = i < a.n;
-    if (!valid) i = a.n - 1;                      // an odd tail: the spare half shadows the last point, writes nothing
+    if (!valid) i = a.n - 1;                      // a ragged tail: spare groups shadow the last point, write nothing
     unsigned* region = lds + half * x2::REGION;
     const int partner_addr = (lane ^ 16) << 2;
-    int sx[x2::NS], sy0[x2::NS];
-    bool sok[x2::NS];
+    int sx[NS], sy0[NS];
+    bool sok[NS];
 #pragma unroll
-    for (int s = 0; s < x2::NS; ++s) {
-        const int seg = l32 + 32 * s;
+    for (int s = 0; s < NS; ++s) {
+        const int seg = l32 + GL * s;
         sok[s] = seg < 3 * x2::W;
         const int g = sok[s] ? seg / x2::W : 0;
         sx[s] = sok[s] ? seg - g * x2::W : 0;
@@ -742,8 +756,8 @@ __global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        x2::lk_one(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0, sok,
-                   n_lv, n_it);
+        x2::lk_one<PPW>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0,
+                        sok, n_lv, n_it);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
     }
@@ -815,8 +829,10 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     const unsigned long long span_a = (unsigned long long)prev->slots * (unsigned long long)prev->lv[0].slot_stride * 4ull;
     const unsigned long long span_b = (unsigned long long)next->slots * (unsigned long long)next->lv[0].slot_stride * 4ull;
     const bool x2_ok = a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g') && span_a < 0xf0000000ull && span_b < 0xf0000000ull;
-    if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
-        hipLaunchKernelGGL(lk_track_kernel_x2, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+    if (x2_ok && force && force[0] == 'x' && force[1] == '4')
+        hipLaunchKernelGGL(lk_track_kernel_x2<4>, dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
+    else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
+        hipLaunchKernelGGL(lk_track_kernel_x2<2>, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
     else if (R <= 2) launch_r<2>(a, lds_bytes, st);
     else if (R <= 3) launch_r<3>(a, lds_bytes, st);
