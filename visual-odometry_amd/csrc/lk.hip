@@ -583,7 +583,10 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 staged = true;
             }
         }
-        int Ival[NS][R], Dval[NS][R];
+        // template window in registers.  Cval = 256 - 512 * I is the accumulator seed of the bilinear J sample, so
+        // that (seed + taps) >> 9 is directly diff = J - I ((x - 512 k) >> 9 == (x >> 9) - k for arithmetic
+        // shifts).  (Pairing pixels for v_dot2 in the b1 / b2 sums was measured slower: v_dot2 is half rate.)
+        int Cval[NS][R], Dval[NS][R];
         float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
@@ -612,7 +615,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                     const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
                     const int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
                     const int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
-                    Ival[s][k] = iv;
+                    Cval[s][k] = 256 - (iv << 9);
                     Dval[s][k] = (ix & 0xffff) | (iy << 16);
                     a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
                 }
@@ -664,8 +667,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 for (int r = 0; r <= R; ++r) P[r] = lp[r * RS];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                    const int diff = jv - Ival[s][k];
+                    const int diff = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[s][k])) >> 9;
                     b1 += diff * (int)(short)Dval[s][k];
                     b2 += diff * (Dval[s][k] >> 16);
                 }
@@ -707,10 +709,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 for (int r = 0; r <= R; ++r) P[r] = lp[r * RS];
                 int ss = 0;
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                    ss += abs(jv - Ival[s][k]);
-                }
+                for (int k = 0; k < R; ++k) ss += abs(sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[s][k])) >> 9);
                 se += sok[s] ? ss : 0;
             }
             err = half_sum_to_float<PPW>(se, partner_addr) / (float)(32 * w * h);
