@@ -34,12 +34,12 @@ MIN_EIG = 1e-3
 N_FRAMES = 8
 
 
-# HBM-side bytes of one lk_track_kernel<7> launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# HBM-side bytes of one LK launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 # over this very command (profiles/r01_pmc_bench_fetch.txt, r01_pmc_bench_write.txt; KB x 1024), keyed by
 # (pairs per launch, points per pair).  The kernel's loads are narrow (2- and 8-byte gathers), a pattern for
 # which the guide gives no gfx950 FETCH_SIZE correction, so the raw value is reported; it is well below the
 # algorithmic bytes because the patches are served from L2 / MALL.
-LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((403914.4 + 3610.0) * 1024), (1, 2000): int((18063.6 + 142.8) * 1024)}
+LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((432824.2 + 1801.1) * 1024), (1, 2000): int((18062.4 + 142.7) * 1024)}
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
@@ -228,7 +228,8 @@ def main():
     if rank == 0:
         alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_launch[1]), float(cnt_launch[2]))
         achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
-        kernel = "lk_track_kernel<7> (fwd + bwd + FB check of %d pairs x %d points in one launch)" % (B, n)
+        kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if B * n >= 12288 else "lk_track_kernel<7, 21>"
+        kernel = "%s: fwd + bwd + FB check of %d pairs x %d points in one launch" % (kname, B, n)
         out = {
             "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",
             "value": round(fps, 2),
