@@ -131,6 +131,16 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
                     double min_distance, int block_size, int aperture, int harris, double k,
                     float* d_corners_xy, int capacity, int* h_n_out);
 
+/* ---- candidate bookkeeping ------------------------------------------------
+ * Replaces the new-feature de-duplication of reference continuous.py:408-416
+ *     cdist(features_current, existing_features) -> np.min(axis=1) -> > THRESHOLD_NEW_KEYPOINTS
+ * without building the distance matrix: d_mask[i] = 1 iff every existing point is farther than
+ * `threshold` from feature i, decided exactly as scipy's float64 Euclidean cdist decides it
+ * (NaN distances give 0).  Points are (x,y) f32 pairs; n_existing == 0 gives all ones (numpy itself
+ * raises on the empty reduction; the Python mirror keeps that).  Asynchronous on the ctx stream. */
+int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
+                          const float* d_existing_xy, int n_existing, double threshold, uint8_t* d_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,3 +188,15 @@ def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
     if n.value == 0:
         return None
     return out[: n.value].reshape(-1, 1, 2).copy()
+
+
+def new_feature_mask(features_current, existing_features, threshold=15):
+    """Restatement of reference continuous.py:408-413 (scipy.spatial.distance.cdist, float64 Euclidean,
+    then np.min(axis=1) > threshold) in plain numpy: d = sqrt(dx*dx + dy*dy) per pair, one rounding per
+    operation.  PINNED: tests/test_oracle_cpu.py checks it against scipy's cdist itself."""
+    f = np.asarray(features_current, dtype=np.float64).reshape(-1, 2)
+    e = np.asarray(existing_features, dtype=np.float64).reshape(-1, 2)
+    dx = f[:, None, 0] - e[None, :, 0]
+    dy = f[:, None, 1] - e[None, :, 1]
+    d = np.sqrt(dx * dx + dy * dy)
+    return np.min(d, axis=1) > threshold

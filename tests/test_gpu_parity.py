@@ -489,3 +489,28 @@ def test_ragged_batch_of_sequences_in_one_launch(fe):
         assert np.array_equal(nxt[o:o + k].T, t0) and np.array_equal(st[o:o + k], s0) and np.array_equal(err[o:o + k], e0)
         o += k
     pyr.free()
+
+
+# ------------------------------------------------------------------ candidate bookkeeping
+def test_new_feature_mask_matches_scipy_cdist_rule(fe):
+    from scipy.spatial.distance import cdist
+    from test_oracle_cpu import dedup_cases
+    for f, e, thr in dedup_cases():
+        with np.errstate(invalid="ignore"):
+            ref = np.min(cdist(f, e), axis=1) > thr
+            assert np.array_equal(oracle.new_feature_mask(f, e, thr), ref)
+        got = fe.new_feature_mask(f, e, thr)
+        assert got.dtype == bool and np.array_equal(got, ref), (f.shape, e.shape, thr)
+    # the reference's use: detections of the current frame against candidates + landmarks
+    a = _seq(376, 1241, 0, 1)[0]
+    det = oracle.goodFeaturesToTrack(a, 1000, 0.01, 10).reshape(-1, 2)
+    rng = np.random.default_rng(2)
+    existing = np.vstack([det[::3] + rng.normal(0, 6, det[::3].shape).astype(np.float32), (rng.random((400, 2)) * [1241, 376]).astype(np.float32)])
+    new = fe.filter_new_features(det, existing, 15)
+    ref = det[np.min(cdist(det, existing), axis=1) > 15].T
+    assert new.shape == ref.shape and np.array_equal(new, ref) and 0 < new.shape[1] < det.shape[0]
+    assert fe.new_feature_mask(np.empty((0, 2), np.float32), existing).shape == (0,)
+    with pytest.raises(ValueError):
+        fe.new_feature_mask(det, np.empty((0, 2), np.float32))
+    for bad_thr in (np.inf, np.nan):
+        assert not fe.new_feature_mask(det[:10], existing, bad_thr).any()

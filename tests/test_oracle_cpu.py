@@ -209,3 +209,41 @@ def test_golden_fixtures():
     assert np.array_equal(n, z["lk_next"]) and np.array_equal(s, z["lk_status"]) and np.array_equal(e, z["lk_err"])
     t, s, e = oracle.track_keypoints(z["pts"].T, a, b, (11, 11), 2)
     assert np.array_equal(t, z["fb_next"]) and np.array_equal(s, z["fb_status"])
+
+
+# ------------------------------------------------------------------ candidate bookkeeping
+def dedup_cases():
+    """Feature / existing point sets incl. distances exactly at, one ulp above and below the threshold."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for nf, ne in ((1, 1), (7, 3), (300, 900), (1000, 2500)):
+        f = (rng.random((nf, 2)) * [1241, 376]).astype(np.float32)
+        e = (rng.random((ne, 2)) * [1241, 376]).astype(np.float32)
+        cases.append((f, e, 15))
+    # exact 9-12-15 and 8-15-17 triangles: distance == threshold must be rejected
+    f = np.float32([[100, 100], [100, 100], [50, 50], [50, 50]])
+    e = np.float32([[109, 112], [400, 300]])
+    cases.append((f, e, 15))
+    cases.append((np.float32([[0, 0], [8, 15], [3, 4]]), np.float32([[8, 15], [0, 0]]), 17))
+    # one float32 ulp around the boundary, and a fractional threshold
+    base = np.float32([[200, 200]])
+    near = np.float32([[209, np.nextafter(np.float32(212), np.float32(300))], [209, np.nextafter(np.float32(212), np.float32(0))], [209, 212]])
+    for row in near:
+        cases.append((base, row.reshape(1, 2), 15))
+    cases.append((f, e, 14.999999999999998))
+    cases.append((f, e, 15.000000000000002))
+    cases.append((f, e, 0.0))
+    cases.append((f, e, -1.0))
+    cases.append((np.float32([[1, 1], [np.nan, 2], [np.inf, 0]]), np.float32([[100, 100], [5, 5]]), 3))
+    return cases
+
+
+def test_new_feature_mask_restatement_is_pinned_by_scipy_cdist():
+    """This row is NOT parity-unpinned: scipy is importable here, so the numpy restatement of
+    continuous.py:408-413 is checked against scipy.spatial.distance.cdist itself."""
+    from scipy.spatial.distance import cdist
+    for f, e, thr in dedup_cases():
+        with np.errstate(invalid="ignore"):
+            ref = np.min(cdist(f, e), axis=1) > thr
+            got = oracle.new_feature_mask(f, e, thr)
+        assert np.array_equal(got, ref), (f.shape, e.shape, thr)

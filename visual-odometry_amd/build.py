@@ -3,7 +3,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "pyramid.hip", "lk.hip", "corners.hip"]
+SOURCES = ["api.hip", "pyramid.hip", "lk.hip", "corners.hip", "bookkeeping.hip"]
 # -ffp-contract=off: the float steps must round exactly like the CPU oracle (no fused multiply-add)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 

@@ -324,4 +324,15 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
                           harris, k, d_corners_xy, capacity, h_n_out);
 }
 
+int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
+                          const float* d_existing_xy, int n_existing, double threshold, uint8_t* d_mask) {
+    if (!ctx) { vofe_set_error("vofe_new_feature_mask: ctx is NULL"); return VOFE_E_ARG; }
+    if (n_features < 0 || n_existing < 0) { vofe_set_error("vofe_new_feature_mask: negative count"); return VOFE_E_ARG; }
+    if ((n_features > 0 && (!d_features_xy || !d_mask)) || (n_existing > 0 && !d_existing_xy)) {
+        vofe_set_error("vofe_new_feature_mask: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_xy, n_existing, threshold, d_mask);
+}
+
 }  // extern "C"

@@ -59,6 +59,9 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
                              unsigned* d_max_keys, const uint8_t* d_mask);
+int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
+                                 const float* d_existing_xy, int n_existing, double threshold,
+                                 uint8_t* d_mask);
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,

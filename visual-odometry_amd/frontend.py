@@ -231,6 +231,30 @@ class FrontEnd:
             return None
         return host[: n.value].copy().reshape(-1, 1, 2)
 
+    def new_feature_mask(self, features_current, existing_features, threshold=15):
+        """continuous.py:408-413: cdist(features_current, existing_features) -> min over existing -> > threshold,
+        without the distance matrix.  (N,2) and (M,2) points (numpy or CUDA tensors); returns a bool mask (N,)."""
+        f = features_current if isinstance(features_current, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(np.asarray(features_current, dtype=np.float32).reshape(-1, 2)))
+        e = existing_features if isinstance(existing_features, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(np.asarray(existing_features, dtype=np.float32).reshape(-1, 2)))
+        if f.dtype != torch.float32 or e.dtype != torch.float32:
+            raise error(-1, "points must be float32 (x, y) pairs")
+        if f.shape[0] and e.shape[0] == 0:
+            # np.min over an empty axis: numpy raises, and so does the reference line
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        f, e = f.to(self.device).contiguous(), e.to(self.device).contiguous()
+        mask = torch.empty(f.shape[0], dtype=torch.uint8, device=self.device)
+        _lib.check(self.L.vofe_new_feature_mask(self.ctx, f.data_ptr(), f.shape[0], e.data_ptr(), e.shape[0],
+                                                float(threshold), mask.data_ptr()))
+        return mask.cpu().numpy().astype(bool)
+
+    def filter_new_features(self, features_current, existing_features, threshold=15):
+        """continuous.py:408-416 as one call: the (2,K) array of detections farther than `threshold` from every
+        existing point."""
+        fc = np.asarray(features_current, dtype=np.float32).reshape(-1, 2)
+        return fc[self.new_feature_mask(fc, existing_features, threshold)].T
+
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):
         """images: CUDA uint8 (B,H,W).  Returns (corners CUDA f32 (B,maxCorners,2), counts list)."""
