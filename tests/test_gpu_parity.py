@@ -456,13 +456,14 @@ def test_full_size_config_front_end_frame(fe, cfg, md):
     assert (d[sb.ravel() == 1] < 1.0).all()
 
 
-def test_ragged_batch_of_sequences_in_one_launch(fe):
+@pytest.mark.parametrize("kernel", ["x1", "x2", "x4"])
+def test_ragged_batch_of_sequences_in_one_launch(fe, monkeypatch, kernel):
     """configs[3] batching: B pairs in one pyramid object, points of all pairs in ONE launch with a per-point
     image index (ragged: different counts per pair, one pair with none) == the per-pair results."""
-    import ctypes as C
     import torch
     from visual_odometry_amd import _lib
     from visual_odometry_amd.frontend import Pyramid
+    monkeypatch.setenv("VOFE_LK", kernel)
     H, W, B = 120, 200, 4
     pairs = [_seq(H, W, 60 + s, 2) for s in range(B)]
     counts = [90, 0, 37, 150]
