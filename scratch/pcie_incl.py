@@ -19,6 +19,21 @@ t0 = time.perf_counter()
 for i in range(K): trk.track(fr[i % 8], pts)
 dt = (time.perf_counter() - t0) / K
 print("SequenceTracker.track, numpy in / numpy out (1 image upload): %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
+trk.reset(fr[0]); trk.prefetch(fr[1])
+t0 = time.perf_counter()
+for i in range(K):
+    cur = fr[(i + 1) % 8]
+    out = trk.track(cur, pts)
+    trk.prefetch(fr[(i + 2) % 8])          # overlaps with whatever the caller does next (here: nothing)
+dt = (time.perf_counter() - t0) / K
+print("SequenceTracker.track with prefetch of the next frame: %.1f us/frame -> %.0f frames/s" % (dt * 1e6, 1 / dt))
+import torch
+tt = 0.0
+for i in range(K):
+    cur = fr[(i + 1) % 8]
+    trk.prefetch(cur); torch.cuda.synchronize()
+    t0 = time.perf_counter(); out = trk.track(cur, pts); tt += time.perf_counter() - t0
+print("  of which inside track() when the frame was prefetched earlier: %.1f us" % (tt / K * 1e6))
 t0 = time.perf_counter()
 for i in range(K): fe.goodFeaturesToTrack(fr[i % 8], n, 0.01, 7)
 dt = (time.perf_counter() - t0) / K

@@ -1,0 +1,47 @@
+// VALU instruction issue rates on gfx950 (cycles per wave64 instruction per SIMD, saturated)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef short ss2 __attribute__((ext_vector_type(2)));
+#define REP8(x) x x x x x x x x
+template <int OP>
+__global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
+    int r0 = threadIdx.x + a0, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3, r4 = r0 + 11, r5 = r0 + 13, r6 = r0 + 17, r7 = r0 + 19;
+    const int a = a0 | 0x10001, b = b0 | 0x20003;
+    float f0 = r0, f1 = r1, f2 = r2, f3 = r3, f4 = r4, f5 = r5, f6 = r6, f7 = r7;
+    const float fa = a0 * 1e-3f + 1.0001f, fb = b0 * 1e-3f + 0.5f;
+    for (int i = 0; i < n; ++i) {
+        if (OP == 0) { REP8(r0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r0, false); r1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r1, false); r2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r2, false); r3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r3, false);) }
+        if (OP == 1) { REP8(r0 = __mul24(r0, a) + b; r1 = __mul24(r1, a) + b; r2 = __mul24(r2, a) + b; r3 = __mul24(r3, a) + b;) }
+        if (OP == 2) { REP8(r0 = r0 * a + b; r1 = r1 * a + b; r2 = r2 * a + b; r3 = r3 * a + b;) }
+        if (OP == 3) { REP8(f0 = f0 * fa + fb; f1 = f1 * fa + fb; f2 = f2 * fa + fb; f3 = f3 * fa + fb;) }
+        if (OP == 4) { REP8(r0 = (r0 >> 9) - a; r1 = (r1 >> 9) - a; r2 = (r2 >> 9) - a; r3 = (r3 >> 9) - a;) }
+        if (OP == 5) { REP8(r0 = __builtin_amdgcn_perm(r0, a, 0x05040100u) ^ b; r1 = __builtin_amdgcn_perm(r1, a, 0x05040100u) ^ b; r2 = __builtin_amdgcn_perm(r2, a, 0x05040100u) ^ b; r3 = __builtin_amdgcn_perm(r3, a, 0x05040100u) ^ b;) }
+        if (OP == 6) { REP8(f0 = __builtin_rintf(f0 * fa); f1 = __builtin_rintf(f1 * fa); f2 = __builtin_rintf(f2 * fa); f3 = __builtin_rintf(f3 * fa);) }
+        if (OP == 7) { REP8(r0 += __builtin_amdgcn_update_dpp(0, r0, 0x128, 0xF, 0xF, false); r1 += __builtin_amdgcn_update_dpp(0, r1, 0x124, 0xF, 0xF, false); r2 += __builtin_amdgcn_update_dpp(0, r2, 0x122, 0xF, 0xF, false); r3 += __builtin_amdgcn_update_dpp(0, r3, 0x121, 0xF, 0xF, false);) }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
+}
+template <int OP> void run(const char* name, int* d, int ops_per_iter) {
+    const int blocks = 256 * 8, n = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, n, 1, 2);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, n, 1, 2);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // waves per SIMD = blocks*4/1024 ; instr per wave = n*ops_per_iter
+    const double instr_per_simd = (double)blocks * 4 / 1024 * n * ops_per_iter;
+    printf("%-28s %.3f ms  -> %.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", name, ms, ms * 1e6 / instr_per_simd);
+}
+int main() {
+    int* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+    run<3>("v_fma_f32 (reference)", d, 32);
+    run<0>("v_dot2c_i32_i16", d, 32);
+    run<1>("v_mul_i32_i24 + v_add (2 ops)", d, 64);
+    run<2>("v_mul_lo_u32 + add (2 ops)", d, 64);
+    run<4>("v_ashr + v_sub (2 ops)", d, 64);
+    run<5>("v_perm + v_xor (2 ops)", d, 64);
+    run<6>("v_mul_f32 + v_rndne (2 ops)", d, 64);
+    run<7>("v_add_dpp (+nops)", d, 32);
+    return 0;
+}

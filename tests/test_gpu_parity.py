@@ -424,6 +424,20 @@ def test_sequence_tracker_matches_per_call_path(fe):
         assert np.array_equal(det, oracle.goodFeaturesToTrack(frames[t], 200, 0.01, 7))
         land, cand = lp[:, ls == 1], cp[:, cs == 1]        # carry the survivors, as process_frame does
     trk.close()
+    # ingest overlap: prefetching the next frame changes nothing in the results
+    trk = SequenceTracker(H, W, winSize=(21, 21), maxLevel=3, frontend=fe)
+    trk.prefetch(frames[0])
+    trk.reset(frames[0])
+    pts0 = (rng.random((2, 120)) * [[W - 1], [H - 1]]).astype(np.float32)
+    for t in range(1, 4):
+        trk.prefetch(frames[t])
+        (p1, s1, e1), = trk.track(frames[t], pts0)
+        ref = oracle.track_keypoints(pts0, frames[t - 1], frames[t], nthreads=8)
+        assert np.array_equal(p1, ref[0]) and np.array_equal(s1, ref[1]) and np.array_equal(e1, ref[2])
+    trk.prefetch(frames[1])                                 # a prefetched frame that is then not the one passed
+    (p1, s1, e1), = trk.track(frames[0], pts0)
+    assert np.array_equal(s1, oracle.track_keypoints(pts0, frames[3], frames[0], nthreads=8)[1])
+    trk.close()
     with pytest.raises(Exception):
         SequenceTracker(H, W, frontend=fe).track(frames[0], land)
 

@@ -30,10 +30,35 @@ class SequenceTracker:
         self.pyr = Pyramid(self.fe, 2, self.h, self.w, winSize, maxLevel, True)
         self.frame_index = -1                     # index of the frame held in slot frame_index & 1
         self._img = [None, None]                  # device images of the two slots (for detect())
+        self._stage, self._stage_k, self._copy_stream, self._prefetched = None, 0, None, None
 
     # -- frames ----------------------------------------------------------------------------------
+    def prefetch(self, img_next):
+        """Image ingest overlap: start the upload of the NEXT frame (pinned staging buffer,
+        asynchronous copy on a side stream) while the caller still works on the current one -- e.g. right after
+        track() returns, before the CPU-side PnP/triangulation of reference continuous.py.  The following
+        track(img_next, ...) / reset(img_next) call picks the device copy up if it is handed the same array."""
+        a = np.asarray(img_next)
+        if a.dtype != np.uint8 or a.shape != (self.h, self.w):
+            raise error(-1, "prefetch: need a uint8 frame of %dx%d" % (self.w, self.h))
+        if self._stage is None:
+            self._stage = [torch.empty((self.h, self.w), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._copy_stream = torch.cuda.Stream(device=self.fe.device)
+        k = self._stage_k = 1 - self._stage_k
+        self._stage[k].numpy()[...] = a                       # host copy into pinned memory
+        with torch.cuda.stream(self._copy_stream):
+            d = self._stage[k].to(self.fe.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        self._prefetched = (a, d, ev)
+
     def _push(self, img):
-        d = self.fe.to_device(img)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is img:
+            torch.cuda.current_stream(self.fe.device).wait_event(pre[2])
+            d = pre[1]
+        else:
+            d = self.fe.to_device(img)
         if tuple(d.shape) != (self.h, self.w):
             raise error(-1, "frame size %s does not match the tracker geometry %s" % (tuple(d.shape), (self.h, self.w)))
         self.frame_index += 1
