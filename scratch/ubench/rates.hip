@@ -18,6 +18,9 @@ __global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
         if (OP == 5) { REP8(r0 = __builtin_amdgcn_perm(r0, a, 0x05040100u) ^ b; r1 = __builtin_amdgcn_perm(r1, a, 0x05040100u) ^ b; r2 = __builtin_amdgcn_perm(r2, a, 0x05040100u) ^ b; r3 = __builtin_amdgcn_perm(r3, a, 0x05040100u) ^ b;) }
         if (OP == 6) { REP8(f0 = __builtin_rintf(f0 * fa); f1 = __builtin_rintf(f1 * fa); f2 = __builtin_rintf(f2 * fa); f3 = __builtin_rintf(f3 * fa);) }
         if (OP == 7) { REP8(r0 += __builtin_amdgcn_update_dpp(0, r0, 0x128, 0xF, 0xF, false); r1 += __builtin_amdgcn_update_dpp(0, r1, 0x124, 0xF, 0xF, false); r2 += __builtin_amdgcn_update_dpp(0, r2, 0x122, 0xF, 0xF, false); r3 += __builtin_amdgcn_update_dpp(0, r3, 0x121, 0xF, 0xF, false);) }
+        if (OP == 8) { REP8(asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b));) }
+        if (OP == 9) { REP8(asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r0) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r1) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r2) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r3) : "v"(a));) }
+        if (OP == 10) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
 }
@@ -43,5 +46,8 @@ int main() {
     run<5>("v_perm + v_xor (2 ops)", d, 64);
     run<6>("v_mul_f32 + v_rndne (2 ops)", d, 64);
     run<7>("v_add_dpp (+nops)", d, 32);
+    run<8>("v_mad_i32_i24", d, 32);
+    run<9>("v_mul_i32_i24", d, 32);
+    run<10>("v_add3_u32", d, 32);
     return 0;
 }
