@@ -586,7 +586,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         // template window in registers.  Cval = 256 - 512 * I is the accumulator seed of the bilinear J sample, so
         // that (seed + taps) >> 9 is directly diff = J - I ((x - 512 k) >> 9 == (x >> 9) - k for arithmetic
         // shifts).  (Pairing pixels for v_dot2 in the b1 / b2 sums was measured slower: v_dot2 is half rate.)
-        int Cval[NS][R], Dval[NS][R];
+        // Ix and Iy stay in separate registers: v_mad_i32_i24 (4 cycles) per product instead of an SDWA multiply
+        // plus a share of a 3-operand add.
+        int Cval[NS][R], IXv[NS][R], IYv[NS][R];
         float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
@@ -616,7 +618,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                     const int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
                     const int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
                     Cval[s][k] = 256 - (iv << 9);
-                    Dval[s][k] = (ix & 0xffff) | (iy << 16);
+                    IXv[s][k] = ix; IYv[s][k] = iy;
                     a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
                 }
             }
@@ -668,8 +670,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const int diff = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[s][k])) >> 9;
-                    b1 += diff * (int)(short)Dval[s][k];
-                    b2 += diff * (Dval[s][k] >> 16);
+                    b1 += diff * IXv[s][k];
+                    b2 += diff * IYv[s][k];
                 }
             }
             float fb1, fb2;
