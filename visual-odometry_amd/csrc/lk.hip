@@ -48,9 +48,8 @@ struct LKArgs {
 };
 
 __device__ __forceinline__ int floor_i(float v) {
-    if (!(v > -1073741824.f && v < 1073741824.f)) return INT_MIN;
-    int i = (int)v;
-    return i - ((float)i > v);
+    const int i = (int)__builtin_floorf(v);                              // v_floor_f32 + v_cvt_i32_f32, exact below 2^30
+    return __builtin_fabsf(v) < 1073741824.f ? i : INT_MIN;              // NaN / huge -> INT_MIN (fails every bounds test)
 }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
 
