@@ -21,6 +21,13 @@ __global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
         if (OP == 8) { REP8(asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b));) }
         if (OP == 9) { REP8(asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r0) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r1) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r2) : "v"(a)); asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r3) : "v"(a));) }
         if (OP == 10) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b));) }
+        if (OP == 11) { REP8(asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(r0) : "v"(a)); asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(r1) : "v"(a)); asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(r2) : "v"(a)); asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(r3) : "v"(a));) }
+        if (OP == 12) { REP8(asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(r0) : "v"(a)); asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(r1) : "v"(a)); asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(r2) : "v"(a)); asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(r3) : "v"(a));) }
+        if (OP == 13) { REP8(asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(r0) : "v"(a)); asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(r1) : "v"(a)); asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(r2) : "v"(a)); asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(r3) : "v"(a));) }
+        if (OP == 14) { REP8(asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(r0)); asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(r1)); asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(r2)); asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(r3));) }
+        if (OP == 15) { REP8(asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r0)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r1)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r2)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r3));) }
+        if (OP == 16) { REP8(asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r0) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r1) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r2) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r3) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r4) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r5) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r6) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r7) : "v"(a));) }
+        if (OP == 17) { REP8(asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r4) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r5) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r6) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r7) : "v"(a), "v"(b));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
 }
@@ -49,5 +56,12 @@ int main() {
     run<8>("v_mad_i32_i24", d, 32);
     run<9>("v_mul_i32_i24", d, 32);
     run<10>("v_add3_u32", d, 32);
+    run<11>("v_pack_b32_f16", d, 32);
+    run<12>("v_alignbit_b32", d, 32);
+    run<13>("v_lshl_or_b32", d, 32);
+    run<14>("v_cvt_f32_ubyte1", d, 32);
+    run<15>("asm v_ashrrev (4 chains)", d, 32);
+    run<16>("asm v_sub_u32 (8 chains)", d, 64);
+    run<17>("asm v_mad_i32_i24 (8 chains)", d, 64);
     return 0;
 }
