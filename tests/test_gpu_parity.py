@@ -529,3 +529,52 @@ def test_new_feature_mask_matches_scipy_cdist_rule(fe):
         fe.new_feature_mask(det, np.empty((0, 2), np.float32))
     for bad_thr in (np.inf, np.nan):
         assert not fe.new_feature_mask(det[:10], existing, bad_thr).any()
+
+
+# ------------------------------------------------------------------ seeded randomised differential sweeps
+def test_randomised_lk_sweep_all_window_shapes(fe):
+    """40 random (image size, window, levels, criteria, flags) combinations: every row-group template of the
+    run-time-geometry kernel (windows 3..64 wide, 3..64 tall) against the oracle, bit for bit."""
+    rng = np.random.default_rng(2024)
+    seen_r = set()
+    for case in range(40):
+        h, w = int(rng.integers(48, 260)), int(rng.integers(48, 320))
+        ww, wh = int(rng.integers(3, 65)), int(rng.integers(3, 65))
+        if case < 10:                                   # make sure the extremes are in
+            ww, wh = [(3, 3), (64, 64), (64, 3), (3, 64), (5, 41), (33, 7), (21, 22), (22, 21), (13, 13), (47, 31)][case]
+        lvl = int(rng.integers(0, 4))
+        a, b = _seq(h, w, 300 + case)
+        pts = np.concatenate([(rng.random((40, 2)) * [w - 1, h - 1]), rng.normal(0, 30, (6, 2)) + [w, h]]).astype(np.float32)
+        crit = [(3, 30, 0.01), (1, 7, 0.0), (2, 0, 0.05), (3, 12, 0.2)][case % 4]
+        flags = [0, 8, 4, 0][case % 4]
+        init = (pts + rng.normal(0, 1.5, pts.shape)).astype(np.float32) if flags & 4 else None
+        mineig = [1e-4, 1e-3, 1e-2][case % 3]
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, (ww, wh), lvl, crit, flags, mineig, nthreads=8)
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (ww, wh), lvl, crit, flags, mineig)
+        assert np.array_equal(s0, s1), (case, h, w, ww, wh, lvl)
+        assert np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True), (case, h, w, ww, wh, lvl)
+        groups = min(64 // ww, wh)
+        seen_r.add(-(-wh // groups))
+    assert len(seen_r) >= 12
+
+
+def test_randomised_gftt_sweep(fe):
+    """40 random detector configurations (size, quality, minDistance incl. 0 and large, maxCorners, mask, Harris)."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        h, w = int(rng.integers(20, 300)), int(rng.integers(20, 400))
+        a = _seq(h, w, 500 + case, 1)[0]
+        if case % 7 == 0:
+            a = (a // 32 * 32).astype(np.uint8)                       # posterised: plateaus and ties
+        q = float(rng.choice([0.001, 0.01, 0.05, 0.3, 0.9]))
+        md = float(rng.choice([0, 0.7, 1, 2.5, 7, 10, 19, 23.5, 40]))
+        maxc = int(rng.choice([0, 1, 17, 200, 5000]))
+        harris = bool(case % 5 == 0)
+        mask = None
+        if case % 3 == 0:
+            mask = (rng.random((h, w)) > 0.4).astype(np.uint8)
+        got = fe.goodFeaturesToTrack(a, maxc, q, md, mask=mask, useHarrisDetector=harris, k=0.04)
+        ref = oracle.goodFeaturesToTrack(a, maxc, q, md, mask=mask, useHarrisDetector=harris, k=0.04)
+        assert (got is None) == (ref is None), (case, h, w, q, md, maxc)
+        if ref is not None:
+            assert np.array_equal(got, ref), (case, h, w, q, md, maxc, harris)
