@@ -141,6 +141,23 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
 int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
                           const float* d_existing_xy, int n_existing, double threshold, uint8_t* d_mask);
 
+/* Replaces the candidate update of reference continuous.py:391-405 and the triangulation test of :446-448:
+ *     valid = status == 1;  Ci = tracked[:, valid];  Fi = Fi[:, valid];  Ti = Ti[:, valid]
+ *     d = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0));  good = (d > dist_min) & (d < dist_max)   -> kept, in order
+ *     new_landmarks = d > dist_triangulate                                                   -> d_triangulate_out
+ * d_tracked_xy (n,2) f32 and d_status (n) are the outputs of vofe_track_fb; d_first_xy is (n,2) float32
+ * (first_is_f64 == 0) or float64 — numpy evaluates the distance in that type and so does the kernel, with the
+ * same decisions (NaN distances are dropped).  d_transform is (n, transform_dim) float64, transform_dim <= 16
+ * (the reference keeps 12 or 16 numbers per candidate), or NULL.  The kept candidates are written densely, in input
+ * order, to d_tracked_out / d_first_out / d_transform_out / d_triangulate_out (u8), each of which may be the
+ * buffer its input came from; the count goes to *d_count_out (device) and, when h_count_out is not NULL, to the
+ * host after a synchronisation (otherwise the call is asynchronous on the ctx stream). */
+int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status,
+                          const void* d_first_xy, int first_is_f64, const double* d_transform, int transform_dim,
+                          int n, double dist_min, double dist_max, double dist_triangulate, float* d_tracked_out,
+                          void* d_first_out, double* d_transform_out, uint8_t* d_triangulate_out,
+                          int* d_count_out, int* h_count_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,21 @@ def new_feature_mask(features_current, existing_features, threshold=15):
     dy = f[:, None, 1] - e[None, :, 1]
     d = np.sqrt(dx * dx + dy * dy)
     return np.min(d, axis=1) > threshold
+
+
+def filter_candidates(tracked_features, status, Fi, Ti, dist_min=2, dist_max=100, dist_triangulation=15):
+    """Reference continuous.py:391-405 and :446-448, the reference's own numpy expressions on the same arrays (numpy
+    IS the reference's arithmetic for these lines, so this restatement is pinned by construction): compaction by
+    status, travel-distance band, triangulation flag.  Returns (Ci, Fi, Ti, new_landmarks)."""
+    valid_idx = np.where(status == 1)[0]
+    Ci = tracked_features[:, valid_idx]
+    Fi = Fi[:, valid_idx]
+    Ti = Ti[:, valid_idx]
+    distances = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0))
+    good_candidates = (distances > dist_min) & (distances < dist_max)
+    Ci = Ci[:, good_candidates]
+    Fi = Fi[:, good_candidates]
+    Ti = Ti[:, good_candidates]
+    distance_matrix = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0))
+    new_landmarks = distance_matrix > dist_triangulation
+    return Ci, Fi, Ti, new_landmarks

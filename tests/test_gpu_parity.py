@@ -531,6 +531,56 @@ def test_new_feature_mask_matches_scipy_cdist_rule(fe):
         assert not fe.new_feature_mask(det[:10], existing, bad_thr).any()
 
 
+def test_filter_candidates_matches_reference_numpy_expressions(fe):
+    """vofe_candidate_filter vs continuous.py:391-405/446-448 evaluated by numpy itself: same kept set, order, values
+    and triangulation flags, bit for bit, for float32 and float64 first observations."""
+    from test_oracle_cpu import candidate_cases
+    kept = 0
+    for Ci, st, Fi, Ti, a, b, d in candidate_cases():
+        with np.errstate(invalid="ignore", over="ignore"):
+            rc, rf, rt, rtri = oracle.filter_candidates(Ci, st, Fi, Ti, a, b, d)
+        c, f, t, tri = fe.filter_candidates(Ci, st, Fi, Ti, a, b, d)
+        tag = (Ci.shape, Fi.dtype, a, b, d)
+        assert c.shape == rc.shape and c.dtype == np.float32 and f.dtype == Fi.dtype and t.dtype == Ti.dtype, tag
+        assert np.array_equal(c, rc, equal_nan=True) and np.array_equal(f, rf, equal_nan=True), tag
+        assert np.array_equal(t, rt) and tri.dtype == bool and np.array_equal(tri, rtri), tag
+        kept += c.shape[1]
+    assert kept > 3000
+    import visual_odometry_amd as voa
+    with pytest.raises(voa.error):
+        fe.filter_candidates(np.zeros((2, 3)), np.ones(3, np.uint8), np.zeros((2, 3), np.float32), np.zeros((12, 3)))
+    with pytest.raises(voa.error):
+        fe.filter_candidates(np.zeros((2, 3), np.float32), np.ones(3, np.uint8), np.zeros((2, 3), np.float32), np.zeros((17, 3)))
+
+
+def test_filter_candidates_device_resident_after_tracking(fe):
+    """The reference's use: candidates tracked by vofe_track_fb, then compacted in place on the device; the kept
+    columns equal what the reference's numpy lines keep from the host copies."""
+    import torch
+    a, b = _seq(376, 1241, 0, 2)
+    first = oracle.goodFeaturesToTrack(a, 1500, 0.01, 7).reshape(-1, 2)
+    rng = np.random.default_rng(5)
+    prev = (first + rng.normal(0, 8, first.shape)).astype(np.float32)       # candidates have travelled since first seen
+    trk, st, _ = fe.track_keypoints(prev.T, a, b)
+    Ti = rng.normal(0, 1, (12, prev.shape[0]))
+    rc, rf, rt, rtri = oracle.filter_candidates(trk, st, first.T.copy(), Ti)
+    d_c = torch.from_numpy(np.ascontiguousarray(trk.T)).cuda()
+    d_f = torch.from_numpy(first.copy()).cuda()
+    d_t = torch.from_numpy(np.ascontiguousarray(Ti.T)).cuda()
+    d_s = torch.from_numpy(st.copy()).cuda()
+    d_tri = torch.empty(prev.shape[0], dtype=torch.uint8, device="cuda")
+    m = fe.filter_candidates_device(d_c, d_s, d_f, d_t, d_tri)
+    assert m == rc.shape[1] and 100 < m < prev.shape[0]
+    assert np.array_equal(d_c[:m].cpu().numpy().T, rc) and np.array_equal(d_f[:m].cpu().numpy().T, rf)
+    assert np.array_equal(d_t[:m].cpu().numpy().T, rt) and np.array_equal(d_tri[:m].cpu().numpy().astype(bool), rtri)
+    assert rtri.any() and not rtri.all()
+    # no pose matrix: positions only
+    d_c = torch.from_numpy(np.ascontiguousarray(trk.T)).cuda()
+    d_f = torch.from_numpy(first.copy()).cuda()
+    assert fe.filter_candidates_device(d_c, d_s, d_f, None, d_tri) == m
+    assert np.array_equal(d_c[:m].cpu().numpy().T, rc)
+
+
 # ------------------------------------------------------------------ seeded randomised differential sweeps
 def test_randomised_lk_sweep_all_window_shapes(fe):
     """40 random (image size, window, levels, criteria, flags) combinations: every row-group template of the

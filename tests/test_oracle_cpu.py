@@ -247,3 +247,69 @@ def test_new_feature_mask_restatement_is_pinned_by_scipy_cdist():
             ref = np.min(cdist(f, e), axis=1) > thr
             got = oracle.new_feature_mask(f, e, thr)
         assert np.array_equal(got, ref), (f.shape, e.shape, thr)
+
+
+def candidate_cases():
+    """(tracked (2,N) f32, status, Fi (2,N) f32|f64, Ti (D,N), dmin, dmax, dtri) incl. travel distances exactly at and
+    within a few ulps of every threshold, NaN/inf coordinates, empty and all-lost sets."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for n, tdim, fdt in ((1, 12, np.float32), (63, 12, np.float64), (1024, 16, np.float32), (1025, 12, np.float64),
+                         (5000, 12, np.float32), (3000, 12, np.float64)):
+        Fi = (rng.random((2, n)) * [[1241], [376]]).astype(fdt)
+        ang = rng.random(n) * 2 * np.pi
+        r = np.where(rng.random(n) < 0.5, rng.random(n) * 130, rng.choice([2.0, 15.0, 100.0], n) * (1 + rng.integers(-4, 5, n) * 6e-8))
+        Ci = (Fi.astype(np.float64) + r * np.vstack([np.cos(ang), np.sin(ang)])).astype(np.float32)
+        st = (rng.random(n) < 0.8).astype(np.uint8)
+        Ti = rng.normal(0, 3, (tdim, n))
+        cases.append((Ci, st, Fi, Ti, 2, 100, 15))
+    # integer Pythagorean displacements: distance == threshold exactly (rejected by the strict comparisons)
+    disp = np.array([[0, 2], [2, 0], [60, 80], [9, 12], [12, 9], [3, 4], [0, 0], [28, 96], [0, 100], [1, 2], [80, 60.5]]).T
+    for fdt in (np.float32, np.float64):
+        Fi = np.full((2, disp.shape[1]), 300.0, fdt)
+        Ci = (Fi + disp).astype(np.float32)
+        cases.append((Ci, np.ones(disp.shape[1], np.uint8), Fi, np.arange(12.0 * disp.shape[1]).reshape(12, -1), 2, 100, 15))
+        # ulp sweeps along an axis around each threshold
+        xs = []
+        for t in (2.0, 15.0, 100.0, 0.1, 2.5):
+            x = np.float32(t)
+            lo = x
+            for _ in range(4):
+                lo = np.nextafter(lo, np.float32(0))
+            for _ in range(9):
+                xs.append(lo)
+                lo = np.nextafter(lo, np.float32(1e9))
+        xs = np.float32(xs)
+        Fi = np.zeros((2, xs.size), fdt)
+        Ci = np.vstack([xs, np.zeros_like(xs)]).astype(np.float32)
+        one = np.ones(xs.size, np.uint8)
+        Ti = rng.normal(0, 1, (12, xs.size))
+        cases.append((Ci, one, Fi, Ti, 2, 100, 15))
+        cases.append((Ci, one, Fi, Ti, 0.1, 2.5, 2))
+        cases.append((Ci, one, Fi, Ti, 2.5, 100.0, 0.1))
+        cases.append((Ci, one, Fi, Ti, -1, np.inf, 0))
+        cases.append((Ci, one, Fi, Ti, 0, 1e30, np.nan))
+        # NaN / inf coordinates and statuses other than 0/1
+        Ci = np.float32([[np.nan, 5, np.inf, 10, 20, 30], [0, np.nan, 0, 10, 20, 30]])
+        Fi = np.array([[0, 0, 0, 0, np.inf, 0], [0, 0, 0, 0, 0, 0]], fdt)
+        cases.append((Ci, np.uint8([1, 1, 1, 1, 1, 2]), Fi, rng.normal(0, 1, (12, 6)), 2, 100, 15))
+        cases.append((np.empty((2, 0), np.float32), np.empty(0, np.uint8), np.empty((2, 0), fdt), np.empty((12, 0)), 2, 100, 15))
+        cases.append((Ci, np.zeros(6, np.uint8), Fi, rng.normal(0, 1, (12, 6)), 2, 100, 15))
+    return cases
+
+
+def test_filter_candidates_restatement_is_the_reference_expression():
+    """continuous.py:391-405/446-448 are plain numpy, so the oracle for this row IS the reference's arithmetic; this
+    checks the bookkeeping around it: shapes, dtypes, order, and a hand-worked example."""
+    Ci = np.float32([[10, 13, 70, 19], [10, 14, 90, 22]])
+    Fi = np.float32([[10, 10, 10, 10], [10, 10, 10, 10]])
+    Ti = np.arange(48.0).reshape(12, 4)
+    c, f, t, tri = oracle.filter_candidates(Ci, np.uint8([1, 1, 1, 1]), Fi, Ti)
+    # distances 0, 5, 100, 15 -> kept: 5 and 15; triangulation flag: 15 is not > 15
+    assert np.array_equal(c, Ci[:, [1, 3]]) and np.array_equal(f, Fi[:, [1, 3]]) and np.array_equal(t, Ti[:, [1, 3]])
+    assert tri.tolist() == [False, False] and c.dtype == np.float32 and t.dtype == np.float64
+    with np.errstate(invalid="ignore", over="ignore"):
+        for Ci, st, Fi, Ti, a, b, d in candidate_cases():
+            c, f, t, tri = oracle.filter_candidates(Ci, st, Fi, Ti, a, b, d)
+            assert c.shape[0] == 2 and f.shape == c.shape and t.shape == (Ti.shape[0], c.shape[1]) and tri.shape == (c.shape[1],)
+            assert f.dtype == Fi.dtype and c.shape[1] <= int((st == 1).sum())

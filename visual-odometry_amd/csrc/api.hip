@@ -335,4 +335,31 @@ int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_featu
     return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_xy, n_existing, threshold, d_mask);
 }
 
+int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status,
+                          const void* d_first_xy, int first_is_f64, const double* d_transform, int transform_dim,
+                          int n, double dist_min, double dist_max, double dist_triangulate, float* d_tracked_out,
+                          void* d_first_out, double* d_transform_out, uint8_t* d_triangulate_out,
+                          int* d_count_out, int* h_count_out) {
+    if (h_count_out) *h_count_out = 0;
+    if (!ctx) { vofe_set_error("vofe_candidate_filter: ctx is NULL"); return VOFE_E_ARG; }
+    if (n < 0) { vofe_set_error("vofe_candidate_filter: negative count"); return VOFE_E_ARG; }
+    if (!d_count_out) { vofe_set_error("vofe_candidate_filter: d_count_out is NULL"); return VOFE_E_ARG; }
+    if (d_transform && (transform_dim < 1 || transform_dim > 16)) {
+        vofe_set_error("vofe_candidate_filter: transform_dim must be 1..16, got %d", transform_dim);
+        return VOFE_E_ARG;
+    }
+    if (n > 0 && (!d_tracked_xy || !d_status || !d_first_xy || !d_tracked_out || !d_first_out || !d_triangulate_out ||
+                  (d_transform && !d_transform_out))) {
+        vofe_set_error("vofe_candidate_filter: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    int rc = vofe_launch_candidate_filter(ctx, d_tracked_xy, d_status, d_first_xy, first_is_f64, d_transform, transform_dim, n,
+                                          dist_min, dist_max, dist_triangulate, d_tracked_out, d_first_out, d_transform_out,
+                                          d_triangulate_out, d_count_out);
+    if (rc || !h_count_out) return rc;
+    VOFE_HIP(hipMemcpyAsync(h_count_out, d_count_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VOFE_HIP(hipStreamSynchronize(ctx->stream));
+    return VOFE_OK;
+}
+
 }  // extern "C"

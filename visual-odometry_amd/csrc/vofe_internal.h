@@ -62,6 +62,10 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
                                  const float* d_existing_xy, int n_existing, double threshold,
                                  uint8_t* d_mask);
+int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status, const void* d_first_xy,
+                                 int first_is_f64, const double* d_transform, int tdim, int n, double dist_min,
+                                 double dist_max, double dist_tri, float* d_tracked_out, void* d_first_out,
+                                 double* d_transform_out, uint8_t* d_tri_out, int* d_count_out);
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,

@@ -255,6 +255,62 @@ class FrontEnd:
         fc = np.asarray(features_current, dtype=np.float32).reshape(-1, 2)
         return fc[self.new_feature_mask(fc, existing_features, threshold)].T
 
+    def filter_candidates(self, tracked_features, status, Fi, Ti, dist_min=2, dist_max=100, dist_triangulation=15):
+        """continuous.py:391-405 and :446-448 as one device pass.  tracked_features (2,N) float32 and status (N,) are
+        what `track_keypoints` returned for the candidates, Fi (2,N) float32/float64 their first observations, Ti
+        (12|16,N) the poses at first observation.  Returns (Ci, Fi, Ti, new_landmarks): the candidates with status 1
+        whose travel distance lies strictly between dist_min and dist_max, in the input order and the input dtypes,
+        and the bool mask `distance > dist_triangulation` over them."""
+        c = np.asarray(tracked_features)
+        f = np.asarray(Fi)
+        t = np.asarray(Ti)
+        st = np.asarray(status).reshape(-1)
+        if c.dtype != np.float32:
+            raise error(-1, "tracked_features must be the float32 output of track_keypoints")
+        if f.dtype not in (np.float32, np.float64):
+            raise error(-1, "Fi must be float32 or float64")
+        if c.ndim != 2 or c.shape[0] != 2 or f.shape != c.shape or t.ndim != 2 or t.shape[1] != c.shape[1] \
+                or st.shape[0] != c.shape[1]:
+            raise error(-1, "expected tracked_features (2,N), status (N,), Fi (2,N), Ti (D,N)")
+        if not 1 <= t.shape[0] <= 16:
+            raise error(-1, "Ti must have between 1 and 16 rows")
+        n, tdim = c.shape[1], t.shape[0]
+        dev = self.device
+        d_c = torch.from_numpy(np.ascontiguousarray(c.T)).to(dev)
+        d_f = torch.from_numpy(np.ascontiguousarray(f.T)).to(dev)
+        d_t = torch.from_numpy(np.ascontiguousarray(t.T, dtype=np.float64)).to(dev)
+        d_s = torch.from_numpy(np.ascontiguousarray((st == 1).astype(np.uint8))).to(dev)       # continuous.py:391
+        d_tri = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        m = self.filter_candidates_device(d_c, d_s, d_f, d_t, d_tri, dist_min, dist_max, dist_triangulation)
+        return (d_c[:m].cpu().numpy().T, d_f[:m].cpu().numpy().T, d_t[:m].cpu().numpy().astype(t.dtype).T,
+                d_tri[:m].cpu().numpy().astype(bool))
+
+    def filter_candidates_device(self, tracked_xy, status, first_xy, transform, triangulate_out, dist_min=2, dist_max=100,
+                                 dist_triangulation=15):
+        """Device-resident form: tracked_xy (N,2) f32, status (N,) u8, first_xy (N,2) f32/f64, transform (N,D) f64 or
+        None, all CUDA tensors, compacted IN PLACE; triangulate_out (>=N,) u8 receives the triangulation flags.
+        Returns the number of candidates kept (one synchronisation)."""
+        n = tracked_xy.shape[0]
+        if tracked_xy.dtype != torch.float32 or status.dtype not in (torch.uint8, torch.bool) or \
+                first_xy.dtype not in (torch.float32, torch.float64) or \
+                (transform is not None and transform.dtype != torch.float64) or triangulate_out.dtype != torch.uint8:
+            raise error(-1, "filter_candidates_device: unexpected tensor dtype")
+        for x in (tracked_xy, status, first_xy, transform, triangulate_out):
+            if x is not None and not x.is_contiguous():
+                raise error(-1, "filter_candidates_device: tensors must be contiguous")
+        if first_xy.shape != tracked_xy.shape or status.shape[0] != n or triangulate_out.shape[0] < n or \
+                (transform is not None and transform.shape[0] != n):
+            raise error(-1, "filter_candidates_device: shapes disagree")
+        cnt = torch.empty(1, dtype=torch.int32, device=self.device)
+        m = C.c_int(0)
+        tp = transform.data_ptr() if transform is not None else None
+        _lib.check(self.L.vofe_candidate_filter(
+            self.ctx, tracked_xy.data_ptr(), status.data_ptr(), first_xy.data_ptr(), int(first_xy.dtype == torch.float64),
+            tp, transform.shape[1] if transform is not None else 0, n, float(dist_min), float(dist_max),
+            float(dist_triangulation), tracked_xy.data_ptr(), first_xy.data_ptr(), tp, triangulate_out.data_ptr(),
+            cnt.data_ptr(), C.byref(m)))
+        return m.value
+
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):
         """images: CUDA uint8 (B,H,W).  Returns (corners CUDA f32 (B,maxCorners,2), counts list)."""
