@@ -9,6 +9,8 @@ __global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
     const int a = a0 | 0x10001, b = b0 | 0x20003;
     float f0 = r0, f1 = r1, f2 = r2, f3 = r3, f4 = r4, f5 = r5, f6 = r6, f7 = r7;
     const float fa = a0 * 1e-3f + 1.0001f, fb = b0 * 1e-3f + 0.5f;
+    double d0 = r0, d1 = r1, d2 = r2, d3 = r3;
+    const double da = a0 * 1e-3 + 1.0001, db = b0 * 1e-3 + 0.5;
     for (int i = 0; i < n; ++i) {
         if (OP == 0) { REP8(r0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r0, false); r1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r1, false); r2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r2, false); r3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), r3, false);) }
         if (OP == 1) { REP8(r0 = __mul24(r0, a) + b; r1 = __mul24(r1, a) + b; r2 = __mul24(r2, a) + b; r3 = __mul24(r3, a) + b;) }
@@ -28,8 +30,18 @@ __global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
         if (OP == 15) { REP8(asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r0)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r1)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r2)); asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r3));) }
         if (OP == 16) { REP8(asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r0) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r1) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r2) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r3) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r4) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r5) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r6) : "v"(a)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r7) : "v"(a));) }
         if (OP == 17) { REP8(asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r4) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r5) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r6) : "v"(a), "v"(b)); asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(r7) : "v"(a), "v"(b));) }
+        if (OP == 18) { REP8(asm volatile("v_add_f64 %0, %0, %1" : "+v"(d0) : "v"(da)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(d1) : "v"(da)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(d2) : "v"(da)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(d3) : "v"(da));) }
+        if (OP == 19) { REP8(asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d0) : "v"(da), "v"(db)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d1) : "v"(da), "v"(db)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d2) : "v"(da), "v"(db)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d3) : "v"(da), "v"(db));) }
+        if (OP == 20) { REP8(asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d0) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d1) : "v"(f1)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d2) : "v"(f2)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d3) : "v"(f3));) }
+        if (OP == 21) { REP8(asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f0) : "v"(d0)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f1) : "v"(d1)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f2) : "v"(d2)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f3) : "v"(d3));) }
+        if (OP == 22) { REP8(asm volatile("v_sqrt_f32 %0, %0" : "+v"(f0)); asm volatile("v_sqrt_f32 %0, %0" : "+v"(f1)); asm volatile("v_sqrt_f32 %0, %0" : "+v"(f2)); asm volatile("v_sqrt_f32 %0, %0" : "+v"(f3));) }
+        if (OP == 23) { REP8(asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f0) : "v"(r0)); asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f1) : "v"(r1)); asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f2) : "v"(r2)); asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f3) : "v"(r3));) }
+        if (OP == 24) { REP8(asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r3) : "v"(a), "v"(b));) }
+        if (OP == 25) { REP8(asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r0)); asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r1)); asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r2)); asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r3));) }
+        if (OP == 26) { REP8(asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f0) : "v"(fa)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f1) : "v"(fa)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f2) : "v"(fa)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f3) : "v"(fa));) }
+        if (OP == 27) { REP8(asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r0) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r1) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r2) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r3) : "v"(a));) }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
+    out[blockIdx.x * 256 + threadIdx.x] = (int)(d0 + d1 + d2 + d3) + r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
 }
 template <int OP> void run(const char* name, int* d, int ops_per_iter) {
     const int blocks = 256 * 8, n = 2000;
@@ -63,5 +75,15 @@ int main() {
     run<15>("asm v_ashrrev (4 chains)", d, 32);
     run<16>("asm v_sub_u32 (8 chains)", d, 64);
     run<17>("asm v_mad_i32_i24 (8 chains)", d, 64);
+    run<18>("v_add_f64", d, 32);
+    run<19>("v_fma_f64", d, 32);
+    run<20>("v_cvt_f64_f32", d, 32);
+    run<21>("v_cvt_f32_f64", d, 32);
+    run<22>("v_sqrt_f32", d, 32);
+    run<23>("v_cvt_f32_i32", d, 32);
+    run<24>("v_dot4_u32_u8", d, 32);
+    run<25>("v_bfe_u32", d, 32);
+    run<26>("v_mul_f32", d, 32);
+    run<27>("v_alignbyte_b32", d, 32);
     return 0;
 }

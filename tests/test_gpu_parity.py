@@ -581,6 +581,60 @@ def test_filter_candidates_device_resident_after_tracking(fe):
     assert np.array_equal(d_c[:m].cpu().numpy().T, rc)
 
 
+# ------------------------------------------------------------------ real textures (load-if-present)
+_REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
+
+
+def _real(name):
+    import os
+    path = os.path.join(_REAL_DIR, name)
+    if not os.path.exists(path):
+        pytest.skip("%s is not in this image" % path)
+    from PIL import Image
+    return np.array(Image.open(path).convert("L"), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name", ["camera.png", "brick.png", "coins.png", "text.png", "chessboard_GRAY.png", "moon.png"])
+def test_real_texture_detector_and_pyramid(fe, name):
+    """Photographs, scanned text (saturated 0/255 runs) and a chessboard (exact score ties): corner lists, score map
+    and pyramid identical to the oracle."""
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    img = _real(name)
+    h, w = img.shape
+    assert np.array_equal(fe.corner_score(img), oracle.corner_score(img))
+    for maxc, q, md in ((1000, 0.01, 10), (0, 0.05, 3), (200, 0.01, 0)):
+        ref = oracle.goodFeaturesToTrack(img, maxc, q, md)
+        got = fe.goodFeaturesToTrack(img, maxc, q, md)
+        assert (ref is None) == (got is None), (name, maxc, q, md)
+        if ref is not None:
+            assert got.shape == ref.shape and np.array_equal(got, ref), (name, maxc, q, md)
+    pyr = Pyramid(fe, 1, h, w, (21, 21), 3, True)
+    pyr.build(torch.from_numpy(img).cuda(), 0)
+    for lvl in range(pyr.levels):
+        ref = oracle.pyramid_level(img, lvl)
+        got, der = pyr.download(0, lvl, deriv=True)
+        assert np.array_equal(got, ref) and np.array_equal(der, oracle.scharr(ref)), (name, lvl)
+    pyr.free()
+
+
+def test_real_stereo_pair_tracking(fe):
+    """motorcycle_left/right: a real image pair with large horizontal disparities, occlusions and specular surfaces, so
+    every exit of the tracker is taken (lost at a coarse level, left the image, failed forward-backward check)."""
+    a, b = _real("motorcycle_left.png"), _real("motorcycle_right.png")
+    assert a.shape == b.shape
+    pts = oracle.goodFeaturesToTrack(a, 3000, 0.01, 7).reshape(-1, 2)
+    for win, lvl in (((21, 21), 3), ((31, 31), 4), ((11, 11), 2)):
+        rn, rs, re = oracle.calcOpticalFlowPyrLK(a, b, pts, winSize=win, maxLevel=lvl, criteria=(3, 30, 0.01), minEigThreshold=1e-3)
+        gn, gs, ge = fe.calcOpticalFlowPyrLK(a, b, pts, winSize=win, maxLevel=lvl, criteria=(3, 30, 0.01), minEigThreshold=1e-3)
+        assert np.array_equal(gs, rs) and 0.2 < rs.mean() < 1.0, (win, rs.mean())
+        assert np.array_equal(gn, rn) and np.array_equal(ge, re), win
+    rt, rst, rerr = oracle.track_keypoints(pts.T, a, b)
+    gt, gst, gerr = fe.track_keypoints(pts.T, a, b)
+    assert np.array_equal(gst, rst) and np.array_equal(gt, rt) and np.array_equal(gerr, rerr)
+    assert 0 < rst.sum() < rs.sum()                      # the forward-backward check rejects some forward successes
+
+
 # ------------------------------------------------------------------ seeded randomised differential sweeps
 def test_randomised_lk_sweep_all_window_shapes(fe):
     """40 random (image size, window, levels, criteria, flags) combinations: every row-group template of the

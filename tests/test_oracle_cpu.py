@@ -313,3 +313,68 @@ def test_filter_candidates_restatement_is_the_reference_expression():
             c, f, t, tri = oracle.filter_candidates(Ci, st, Fi, Ti, a, b, d)
             assert c.shape[0] == 2 and f.shape == c.shape and t.shape == (Ti.shape[0], c.shape[1]) and tri.shape == (c.shape[1],)
             assert f.dtype == Fi.dtype and c.shape[1] <= int((st == 1).sum())
+
+
+# ------------------------------------------------------------------ third-party pins of the linear stages
+# cv2 is absent, so the LK/GFTT restatement as a whole stays "parity unpinned"; the stages below are plain linear
+# filters with a published definition, and scipy.ndimage (an independent implementation, in the image) evaluates
+# that definition with 'mirror' = REFLECT_101 borders.  The oracle must agree with it.
+def _texture(h, w, seed):
+    from visual_odometry_amd import synthetic
+    return synthetic.sequence(h, w, seed=seed, n_frames=1)[0]
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (97, 131), (33, 250), (5, 7), (376, 1241)])
+def test_pyr_down_and_scharr_pinned_by_scipy_ndimage(h, w):
+    from scipy import ndimage
+    img = _texture(h, w, h * 7 + w)
+    g = np.array([1, 4, 6, 4, 1], np.int64)
+    full = ndimage.correlate(img.astype(np.int64), np.outer(g, g), mode="mirror")
+    assert np.array_equal(oracle.pyr_down(img), ((full + 128) >> 8)[::2, ::2].astype(np.uint8))
+    sm, df = np.array([3, 10, 3], np.int64), np.array([-1, 0, 1], np.int64)
+    ix = ndimage.correlate(img.astype(np.int64), np.outer(sm, df), mode="mirror")
+    iy = ndimage.correlate(img.astype(np.int64), np.outer(df, sm), mode="mirror")
+    d = oracle.scharr(img)
+    assert np.array_equal(d[..., 0], ix) and np.array_equal(d[..., 1], iy)
+
+
+@pytest.mark.parametrize("harris", [False, True])
+def test_score_map_pinned_by_scipy_ndimage(harris):
+    """Sobel 3x3 / (4*3*255), products, 3x3 unnormalised box sum, min-eigenvalue or Harris response, evaluated by
+    scipy.ndimage in float64: the float32 oracle map agrees to float32 rounding of its intermediate products."""
+    from scipy import ndimage
+    img = _texture(120, 160, 5)
+    a = img.astype(np.float64)
+    sm, df = np.array([1, 2, 1.0]), np.array([-1, 0, 1.0])
+    dx = ndimage.correlate(a, np.outer(sm, df), mode="mirror") / 3060.0
+    dy = ndimage.correlate(a, np.outer(df, sm), mode="mirror") / 3060.0
+    box = lambda m: ndimage.correlate(m, np.ones((3, 3)), mode="mirror")
+    xx, xy, yy = box(dx * dx), box(dx * dy), box(dy * dy)
+    if harris:
+        ref = xx * yy - xy * xy - 0.04 * (xx + yy) ** 2
+    else:
+        ref = (xx * 0.5 + yy * 0.5) - np.sqrt((xx * 0.5 - yy * 0.5) ** 2 + xy * xy)
+    got = oracle.corner_score(img, harris=harris).astype(np.float64)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-6 * scale + 1e-12
+
+
+def test_gftt_candidate_rule_pinned_by_scipy_ndimage():
+    """goodFeaturesToTrack with minDistance 0 and no corner limit returns every candidate: pixels above
+    qualityLevel * max that equal their 3x3 maximum (grey dilation), image border excluded, strongest first with
+    ties in reverse raster order.  The candidate set and order are rebuilt with scipy.ndimage from the oracle's own
+    score map."""
+    from scipy import ndimage
+    for img in (_texture(90, 120, 3), np.kron((np.indices((8, 10)).sum(0) % 2).astype(np.uint8) * 200 + 20, np.ones((9, 9), np.uint8))):
+        S = oracle.corner_score(img)
+        thr = np.float32(np.float64(S.max()) * 0.01)
+        T = np.where(S > thr, S, np.float32(0))
+        loc = (T == ndimage.grey_dilation(T, size=(3, 3), mode="mirror")) & (T != 0)
+        loc[0, :] = loc[-1, :] = False
+        loc[:, 0] = loc[:, -1] = False
+        ys, xs = np.nonzero(loc)
+        order = np.lexsort((-(ys * img.shape[1] + xs), -S[ys, xs].astype(np.float64)))
+        ref = np.stack([xs[order], ys[order]], 1).astype(np.float32)
+        got = oracle.goodFeaturesToTrack(img, 0, 0.01, 0).reshape(-1, 2)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        assert len(ref) > 50
