@@ -17,118 +17,124 @@ namespace {
 struct U4 { unsigned a, b, c, d; } __attribute__((packed, aligned(4)));
 struct U2 { unsigned a, b; } __attribute__((packed, aligned(4)));
 
+// 16 pixels x0 .. x0+15 of an image row under REFLECT_101 (row = pixel 0 of the row, w = image width).  Groups
+// inside the image are one (unaligned) 16-byte load; groups entirely left or right of it are the byte-reversed
+// 16 bytes around the mirror column; only groups that straddle an image edge (or images narrower than the band)
+// gather byte by byte.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint4 load16(const uint8_t* p) {
+    const u32x4 q = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_unaligned*>(
+        (const __attribute__((address_space(1))) uint8_t*)p);
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ uint4 reversed16(uint4 a) {
+    return make_uint4(__builtin_bswap32(a.w), __builtin_bswap32(a.z), __builtin_bswap32(a.y), __builtin_bswap32(a.x));
+}
+__device__ __forceinline__ uint4 mirror16(const uint8_t* row, int x0, int w) {
+    if (x0 >= 0 && x0 + 16 <= w) return load16(row + x0);
+    if (x0 + 15 < 0 && -x0 <= w - 1) return reversed16(load16(row - x0 - 15));
+    if (x0 >= w && 2 * (w - 1) - x0 - 15 >= 0) return reversed16(load16(row + 2 * (w - 1) - x0 - 15));
+    uint8_t b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = row[vofe_reflect101(x0 + i, w)];
+    uint4 v;
+    __builtin_memcpy(&v, b, 16);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // level 0: copy the caller's image into the padded plane and fill the REFLECT_101 border.
-// One thread = 16 consecutive bytes of one padded row.
+// One thread = 16 consecutive bytes of one padded row; threads are numbered over (row, group) so that
+// narrow frames (84 groups per KITTI row) still fill every wavefront.
 __global__ __launch_bounds__(256) void pad_copy_level0(const uint8_t* __restrict__ src, int spitch,
                                                        size_t img_stride, VofeLevel L, int slot0,
-                                                       int win_w, int win_h, int gx0, int ngx) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngx) return;
-    const int y = (int)blockIdx.y - win_h;
+                                                       int win_h, int gx0, int ngx, int items) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int row = it / ngx, g = it - row * ngx;
+    const int y = row - win_h;
     const int x0 = (g + gx0) * 16;
-    const uint8_t* s = src + (size_t)blockIdx.z * img_stride;
-    uint8_t* d = L.I + (long long)(slot0 + (int)blockIdx.z) * L.slot_stride + (long long)y * L.pitch + x0;
+    const uint8_t* s = src + (size_t)blockIdx.y * img_stride;
+    uint8_t* d = L.I + (long long)(slot0 + (int)blockIdx.y) * L.slot_stride + (long long)y * L.pitch + x0;
     const int sy = vofe_reflect101(y, L.h);
-    const uint8_t* srow = s + (size_t)sy * spitch;
-    uint4 v;
-    if (x0 >= 0 && x0 + 16 <= L.w) {
-        __builtin_memcpy(&v, srow + x0, 16);
-    } else {
-        uint8_t b[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) b[i] = srow[vofe_reflect101(x0 + i, L.w)];
-        __builtin_memcpy(&v, b, 16);
-    }
-    *reinterpret_cast<uint4*>(d) = v;
+    *reinterpret_cast<uint4*>(d) = mirror16(s + (size_t)sy * spitch, x0, L.w);
 }
 
 // ---------------------------------------------------------------------------------------------
-// pyrDown: src level (padded, border valid) -> dst level interior + border.
-// One thread = 8 consecutive output pixels of one padded output row.
-__device__ __forceinline__ unsigned byte_of(const unsigned* w, int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
-
-// one reflected-coordinate output pixel (borders, ragged last group)
-__device__ __forceinline__ unsigned pyr_down_px(const uint8_t* __restrict__ sp, int spitch, int rx, int ry) {
-    int acc = 128;
+// pyrDown: interior of the next level plus its two REFLECT_101 border columns on either side.
+// One thread = 8 consecutive output pixels of TWO output rows (7 source rows instead of 10).  A source row
+// arrives as six dwords covering columns 2*X0-4 .. 2*X0+19; the ten 4-byte windows starting at every second
+// column come from v_alignbyte, and one output's row term  w_k * (p[-2] + 4 p[-1] + 6 p[0] + 4 p[1] + p[2])
+// is two v_dot4_u32_u8 accumulations: window j against w_k*(1,4,6,4) and window j+2 against w_k*(1,0,0,0)
+// (w_k*6 <= 36 fits a byte), so the whole 5x5 kernel is accumulated in integers exactly as SURVEY A.3 states it.
+// Source rows are addressed through REFLECT_101 on the row index, so the source needs valid border COLUMNS only
+// (two per side, on its interior rows): level 0 has its full border from pad_copy_level0, and every level
+// written here gets those columns from the threads that own columns 1, 2, w-3 and w-2.  The full border
+// bands of the new levels (LK and Scharr need them) are filled afterwards by one pyramid_borders launch.
+__global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, int slot0, int gpr, int items) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int yp = it / gpr, g = it - yp * gpr;
+    const int X0 = g * 8, Y0 = yp * 2;
+    const uint8_t* sp = S.I + (long long)(slot0 + (int)blockIdx.y) * S.slot_stride + 2 * X0 - 4;
+    unsigned acc[2][8];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int wk = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
-        const uint8_t* r = sp + (long long)(2 * ry - 2 + k) * spitch + 2 * rx;
-        acc += wk * ((int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0]);
-    }
-    return (unsigned)(acc >> 8);
-}
-
-// Rows of the REFLECT_101 border band are copies of interior rows, so every row runs the vector path at
-// the reflected row index.  Column groups outside the image (and the ragged last group) are filled after a
-// block barrier: outside pixels copy the reflected pixel of the same output row, which a thread of the
-// same block has just written (one block spans the row whenever `exchange` is set); only the few
-// in-image pixels of a ragged last group are computed one by one.
-__global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, int slot0, int win_w,
-                                                   int win_h, int gx0, int ngx) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = g < ngx;
-    const int Y = (int)blockIdx.y - win_h;
-    const int ry = vofe_reflect101(Y, Dl.h);
-    const int X0 = (g + gx0) * 8;
-    const long long so = (long long)(slot0 + (int)blockIdx.z) * S.slot_stride;
-    const long long dofs = (long long)(slot0 + (int)blockIdx.z) * Dl.slot_stride;
-    const uint8_t* sp = S.I + so;
-    uint8_t* drow = Dl.I + dofs + (long long)Y * Dl.pitch;
-    const bool full = live && X0 >= 0 && X0 + 8 <= Dl.w;
-    // every reflected column of the bands lands in a complete group of this block's row
-    const bool exchange = gridDim.x == 1 && Dl.w >= 8 - gx0 * 8 && Dl.w >= win_w + 16;
-    unsigned out[8];
-    if (full) {
-        int acc[8];
+    for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 128;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 128;
+    for (int k = 0; k < 7; ++k) {
+        const uint8_t* r = sp + (long long)vofe_reflect101(2 * Y0 - 2 + k, S.h) * S.pitch;
+        const U4 a = *reinterpret_cast<const U4*>(r);
+        const U2 b = *reinterpret_cast<const U2*>(r + 16);
+        const unsigned wv[6] = {a.a, a.b, a.c, a.d, b.a, b.b};
+        unsigned win[10];                          // win[m] = bytes 2+2m .. 5+2m of the row segment
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int wk = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
-            const uint8_t* r = sp + (long long)(2 * ry - 2 + k) * S.pitch + 2 * X0 - 4;
-            unsigned wv[6];
-            U4 a = *reinterpret_cast<const U4*>(r);
-            U2 b = *reinterpret_cast<const U2*>(r + 16);
-            wv[0] = a.a; wv[1] = a.b; wv[2] = a.c; wv[3] = a.d; wv[4] = b.a; wv[5] = b.b;
+        for (int m = 0; m < 10; ++m)
+            win[m] = (m & 1) ? wv[(m + 1) / 2] : __builtin_amdgcn_alignbyte(wv[m / 2 + 1], wv[m / 2], 2);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int t = k - 2 * o;               // tap index of this source row in output row o
+            if (t < 0 || t > 4) continue;
+            const unsigned wk = (t == 0 || t == 4) ? 1u : (t == 2 ? 6u : 4u);
+            const unsigned W = wk * 0x04060401u, E = wk;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c = 4 + 2 * j;
-                int hs = (int)(byte_of(wv, c - 2) + byte_of(wv, c + 2)) + 4 * (int)(byte_of(wv, c - 1) + byte_of(wv, c + 1)) +
-                         6 * (int)byte_of(wv, c);
-                acc[j] += wk * hs;
+                acc[o][j] = __builtin_amdgcn_udot4(win[j], W, acc[o][j], false);
+                acc[o][j] = __builtin_amdgcn_udot4(win[j + 2], E, acc[o][j], false);
             }
         }
+    }
+    const int w = Dl.w;
+    const bool full = X0 + 8 <= w;
+    const bool edge = X0 == 0 || X0 + 8 > w - 3;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = (unsigned)(acc[j] >> 8);
-    } else if (live && !exchange) {
-#pragma unroll 1
-        for (int j = 0; j < 8; ++j) out[j] = pyr_down_px(sp, S.pitch, vofe_reflect101(X0 + j, Dl.w), ry);
-    }
-    if (live && (full || !exchange)) {
-        uint2 o;
-        o.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-        o.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-        *reinterpret_cast<uint2*>(drow + X0) = o;
-    }
-    if (!exchange) return;                          // uniform
-    __threadfence_block();
-    __syncthreads();
-    if (live && !full) {
-        const int wfull = Dl.w & ~7;
-#pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
-            const int x = X0 + j;
-            const int rx = vofe_reflect101(x, Dl.w);
-            out[j] = (x != rx && rx < wfull) ? (unsigned)drow[rx] : pyr_down_px(sp, S.pitch, rx, ry);
+    for (int o = 0; o < 2; ++o) {
+        const int y = Y0 + o;
+        if (y >= Dl.h) break;
+        uint8_t* drow = Dl.I + (long long)(slot0 + (int)blockIdx.y) * Dl.slot_stride + (long long)y * Dl.pitch;
+        unsigned out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = acc[o][j] >> 8;
+        if (full) {
+            uint2 q;
+            q.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+            q.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+            *reinterpret_cast<uint2*>(drow + X0) = q;
         }
-        uint2 o;
-        o.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-        o.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-        *reinterpret_cast<uint2*>(drow + X0) = o;
+        if (edge) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = X0 + j;
+                if (x >= w) continue;
+                if (!full) drow[x] = (uint8_t)out[j];
+                if (x == 1 || x == 2) drow[-x] = (uint8_t)out[j];
+                if (x == w - 2 || x == w - 3) drow[2 * (w - 1) - x] = (uint8_t)out[j];
+            }
+        }
     }
 }
+
+__device__ __forceinline__ unsigned byte_of(const unsigned* w, int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
 
 // ---------------------------------------------------------------------------------------------
 // Scharr derivative of every level in one launch.  One thread = 8 pixels of one row; a block is
@@ -327,29 +333,58 @@ __global__ __launch_bounds__(1024) void pyramid_fused(const uint8_t* __restrict_
     }
 }
 
-// REFLECT_101 border bands of every level in one launch (reads the interiors written by
-// pyramid_fused).  One thread = 16 bytes of one padded row; fully interior groups return at once.
-__global__ __launch_bounds__(256) void pyramid_borders(const VofeLevel* __restrict__ lv, ScharrPlan plan, int slot0,
+// REFLECT_101 border bands of every level in one launch (reads the interiors written before).  One thread =
+// 16 bytes of one padded row; only border groups are enumerated: first the 2*win_h band rows in full, then the
+// left and right band groups of the interior rows (incl. the group that straddles the right image edge).
+struct BorderPlan {
+    int blk_start[VOFE_MAX_LEVELS + 1];
+    int ng[VOFE_MAX_LEVELS];      // 16-byte groups per padded row
+    int nin[VOFE_MAX_LEVELS];     // groups that lie fully inside the image
+    int levels;
+};
+__global__ __launch_bounds__(256) void pyramid_borders(const VofeLevel* __restrict__ lv, BorderPlan plan, int slot0,
                                                        int win_w, int win_h) {
     int level = 0;
     while (level + 1 < plan.levels && (int)blockIdx.x >= plan.blk_start[level + 1]) ++level;
     const VofeLevel L = lv[level];
-    const int b = (int)blockIdx.x - plan.blk_start[level];
-    const int bx = b % plan.blk_x[level], by = b / plan.blk_x[level];
-    const int gx0 = -((win_w + 15) / 16);
-    const int g = bx * 64 + (threadIdx.x & 63) + gx0;
-    const int y = by * 4 + (threadIdx.x >> 6) - win_h;
-    const int x0 = g * 16;
-    if (y >= L.h + win_h || x0 >= L.w + win_w) return;
-    if (y >= 0 && y < L.h && x0 >= 0 && x0 + 16 <= L.w) return;
+    const int ng = plan.ng[level], nin = plan.nin[level], nl = (win_w + 15) / 16;
+    int t = ((int)blockIdx.x - plan.blk_start[level]) * 256 + (int)threadIdx.x;
+    int y, g;
+    const int nband = 2 * win_h * ng;
+    if (t < nband) {
+        const int row = t / ng;
+        g = t - row * ng;
+        y = row < win_h ? row - win_h : L.h + (row - win_h);
+    } else {
+        t -= nband;
+        const int nb = ng - nin;
+        y = t / nb;
+        if (y >= L.h) return;
+        const int k = t - y * nb;
+        g = k < nl ? k : k + nin;
+    }
+    const int x0 = (g - nl) * 16;
     uint8_t* base = L.I + (long long)(slot0 + (int)blockIdx.y) * L.slot_stride;
     const uint8_t* srow = base + (long long)vofe_reflect101(y, L.h) * L.pitch;
-    uint8_t bytes[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bytes[i] = srow[vofe_reflect101(x0 + i, L.w)];
-    uint4 v;
-    __builtin_memcpy(&v, bytes, 16);
-    *reinterpret_cast<uint4*>(base + (long long)y * L.pitch + x0) = v;
+    *reinterpret_cast<uint4*>(base + (long long)y * L.pitch + x0) = mirror16(srow, x0, L.w);
+}
+
+BorderPlan border_plan(const vofe_pyr* pyr, int first_level, int* total_blocks) {
+    BorderPlan plan;
+    plan.levels = pyr->levels;
+    int total = 0;
+    for (int l = 0; l < pyr->levels; ++l) {
+        const int nl = (pyr->win_w + 15) / 16;
+        plan.ng[l] = nl + (pyr->lv[l].w + pyr->win_w + 15) / 16;
+        plan.nin[l] = pyr->lv[l].w / 16;
+        plan.blk_start[l] = total;
+        if (l < first_level) continue;
+        const long long items = 2ll * pyr->win_h * plan.ng[l] + (long long)pyr->lv[l].h * (plan.ng[l] - plan.nin[l]);
+        total += (int)((items + 255) / 256);
+    }
+    plan.blk_start[pyr->levels] = total;
+    *total_blocks = total;
+    return plan;
 }
 
 inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }   // floor division
@@ -384,16 +419,8 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         if (grid.y > 65535) { vofe_set_error("pyramid: image too tall"); return VOFE_E_UNSUPPORTED; }
         hipLaunchKernelGGL(pyramid_fused, grid, dim3(1024), (size_t)off, st, d_img, pitch, img_stride, pyr->d_lv, P, slot0,
                            pyr->with_deriv);
-        ScharrPlan plan;
-        plan.levels = pyr->levels;
         int total = 0;
-        for (int l = 0; l < pyr->levels; ++l) {
-            const int groups = (ww + 15) / 16 + (pyr->lv[l].w + ww + 15) / 16;
-            plan.blk_start[l] = total;
-            plan.blk_x[l] = (groups + 63) / 64;
-            total += plan.blk_x[l] * ((pyr->lv[l].h + 2 * wh + 3) / 4);
-        }
-        plan.blk_start[pyr->levels] = total;
+        const BorderPlan plan = border_plan(pyr, 0, &total);
         hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");
@@ -403,17 +430,23 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         const VofeLevel& L = pyr->lv[0];
         const int gx0 = fdiv(-ww, 16), gx1 = fdiv(L.w + ww - 1, 16);
         const int ngx = gx1 - gx0 + 1;
-        dim3 grid((ngx + 255) / 256, L.h + 2 * wh, count);
-        hipLaunchKernelGGL(pad_copy_level0, grid, dim3(256), 0, st, d_img, pitch, img_stride, L, slot0, ww, wh, gx0, ngx);
+        const long long items = (long long)ngx * (L.h + 2 * wh);
+        if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+        hipLaunchKernelGGL(pad_copy_level0, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img, pitch,
+                           img_stride, L, slot0, wh, gx0, ngx, (int)items);
     }
     for (int l = 1; l < pyr->levels; ++l) {
         const VofeLevel& S = pyr->lv[l - 1];
         const VofeLevel& D = pyr->lv[l];
-        const int gx0 = fdiv(-ww, 8), gx1 = fdiv(D.w + ww - 1, 8);
-        const int ngx = gx1 - gx0 + 1;
-        const int bs = ngx >= 256 ? 256 : (ngx >= 128 ? 128 : 64);
-        dim3 grid((ngx + bs - 1) / bs, D.h + 2 * wh, count);
-        hipLaunchKernelGGL(pyr_down_u8, grid, dim3(bs), 0, st, S, D, slot0, ww, wh, gx0, ngx);
+        const int gpr = (D.w + 7) / 8;
+        const int items = gpr * ((D.h + 1) / 2);
+        hipLaunchKernelGGL(pyr_down_u8, dim3((items + 255) / 256, count), dim3(256), 0, st, S, D, slot0, gpr, items);
+    }
+    if (pyr->levels > 1) {
+        // border bands of levels 1.. (level 0 got its border from pad_copy_level0: no blocks for it)
+        int total = 0;
+        const BorderPlan plan = border_plan(pyr, 1, &total);
+        hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
     }
     if (pyr->with_deriv) {
         ScharrPlan plan;
