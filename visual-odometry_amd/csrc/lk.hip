@@ -431,6 +431,9 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         lk_one<R, WC>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, lds, lane, x, y0, ny, n_lv, n_it, st_acc);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
+        // a keypoint lost by the forward pass stays lost whatever the backward pass finds (continuous.py:158 only
+        // clears status bits) and none of its backward results are returned: skip that pass (wave-uniform)
+        if (!st) break;
     }
     if (a.fb) {
         const float dx = fabsf(p.x - bx), dy = fabsf(p.y - by);
@@ -760,6 +763,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
                         sok, n_lv, n_it);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
+        if (!__any(st)) break;                    // every keypoint of this wavefront was lost going forward
     }
     if (a.fb) {
         const float dx = fabsf(p.x - bx), dy = fabsf(p.y - by);
