@@ -5,7 +5,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "pyramid.hip", "lk.hip", "corners.hip", "bookkeeping.hip"]
 # -ffp-contract=off: the float steps must round exactly like the CPU oracle (no fused multiply-add)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# -dot4-insts: without v_dot2c_i32_i16 (accumulator tied to the destination) the compiler selects the three-source
+# v_dot2_i32_i16, which costs the same issue time and needs no v_mov to keep the seed of every bilinear sample alive
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+         "-Xclang", "-target-feature", "-Xclang", "-dot4-insts"]
 
 
 def build_lib(force=False, verbose=False):
