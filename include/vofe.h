@@ -158,6 +158,20 @@ int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_
                           void* d_first_out, double* d_transform_out, uint8_t* d_triangulate_out,
                           int* d_count_out, int* h_count_out);
 
+/* Replaces the per-candidate triangulation loop of reference continuous.py:450-485 (cv2.triangulatePoints per
+ * candidate, negative-depth test, baseline angle of continuous.py:274-309) with one launch over all candidates.
+ * d_K is the 3x3 intrinsic matrix and d_pose the current 3x4 pose (row-major float64, device); d_cur_xy (n,2) f32,
+ * d_first_xy (n,2) f32/f64 and d_transform (n, transform_dim >= 12) f64 as produced by vofe_candidate_filter;
+ * d_flag_in (n) is its triangulation flag.  d_flag_out[i] = 1 iff candidate i was flagged, its triangulated point
+ * X (rounded to the type of d_first_xy, as OpenCV stores points4D) has X[2] >= -t_first[2], and the angle between
+ * the bearings from the two camera positions exceeds alpha_min (radians); d_xyz (n,3) f64 receives X for every
+ * flagged candidate.  float64 arithmetic; agrees with cv2's SVD to rounding error, not bit for bit.
+ * Asynchronous on the ctx stream. */
+int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy,
+                                const void* d_first_xy, int first_is_f64, const double* d_transform,
+                                int transform_dim, const uint8_t* d_flag_in, int n, double alpha_min,
+                                uint8_t* d_flag_out, double* d_xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,3 +218,75 @@ def filter_candidates(tracked_features, status, Fi, Ti, dist_min=2, dist_max=100
     distance_matrix = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0))
     new_landmarks = distance_matrix > dist_triangulation
     return Ci, Fi, Ti, new_landmarks
+
+
+def _triangulate_points(proj1, proj2, pt1, pt2):
+    """cv2.triangulatePoints for one point pair as OpenCV defines it (modules/calib3d/src/triangulate.cpp): the 4x4
+    DLT matrix rows x*P[2]-P[0], y*P[2]-P[1] per view in float64, right singular vector of the smallest singular
+    value, stored in the type of the first point array.  The SVD here is LAPACK's (numpy), OpenCV's is a one-sided
+    Jacobi: equal up to rounding error and the sign of the vector, which the division by X4[3] removes.  cv2 is not
+    importable here, so this one function is PARITY UNPINNED."""
+    A = np.empty((4, 4))
+    for j, (P, pt) in enumerate(((proj1, pt1), (proj2, pt2))):
+        x, y = float(pt[0]), float(pt[1])
+        A[2 * j] = x * P[2] - P[0]
+        A[2 * j + 1] = y * P[2] - P[1]
+    vt = np.linalg.svd(A)[2]
+    return vt[3].reshape(4, 1).astype(np.asarray(pt1).dtype)
+
+
+def _invert_transformation(T_3x4):
+    """continuous.py:497-522."""
+    T_4x4 = np.eye(4)
+    T_4x4[:3, :4] = T_3x4
+    R = T_4x4[:3, :3]
+    t = T_4x4[:3, 3]
+    R_inv = R.T
+    t_inv = -R_inv @ t
+    T_4x4_inv = np.eye(4)
+    T_4x4_inv[:3, :3] = R_inv
+    T_4x4_inv[:3, 3] = t_inv
+    return T_4x4_inv[:3, :4]
+
+
+def _compute_baseline_angle(point3D, t_cur, t_first):
+    """continuous.py:274-309."""
+    point3D, t_cur, t_first = point3D.flatten(), t_cur.flatten(), t_first.flatten()
+    v_cur = point3D - t_cur
+    v_first = point3D - t_first
+    v_cur = v_cur / np.linalg.norm(v_cur)
+    v_first = v_first / np.linalg.norm(v_first)
+    cos_angle = np.clip(np.dot(v_cur, v_first), -1.0, 1.0)
+    return float(np.arccos(cos_angle))
+
+
+def triangulate_candidates(K, pose, Ci, Fi, Ti, new_landmarks, alpha_deg=1, margins=None):
+    """Reference continuous.py:450-485: the per-candidate loop, with _triangulate_points standing in for
+    cv2.triangulatePoints.  Returns (new_landmarks, points3D (3,P)).  `margins`, when a list, receives per flagged
+    candidate how far its two decisions are from their thresholds (depth margin, angle margin in radians) so tests
+    can leave out candidates whose decision hangs on SVD rounding."""
+    new_landmarks = np.array(new_landmarks, dtype=bool).reshape(-1).copy()
+    K = np.asarray(K, dtype=np.float64).reshape(3, 3)
+    pose = np.asarray(pose, dtype=np.float64)
+    t_cur = pose[:3, 3]
+    points3D = np.empty((3, 0))
+    for idx in range(new_landmarks.shape[0]):
+        if not new_landmarks[idx]:
+            continue
+        Ti_idx_formatted = np.reshape(Ti[:12, idx], (3, 4))
+        proj1 = K @ _invert_transformation(Ti_idx_formatted)
+        proj2 = K @ _invert_transformation(pose[:3, :])
+        point4D_hom = _triangulate_points(proj1, proj2, Fi[:, idx], Ci[:, idx])
+        point3D = point4D_hom[:3] / point4D_hom[3]
+        t_idx = Ti_idx_formatted[:3, 3]
+        alpha = _compute_baseline_angle(point3D, t_cur, t_idx)
+        if margins is not None:
+            margins.append((idx, float(point3D[2, 0]) + t_idx[2], abs(alpha) - np.deg2rad(alpha_deg)))
+        if point3D[2] < -t_idx[2]:
+            new_landmarks[idx] = False
+            continue
+        if abs(alpha) > np.deg2rad(alpha_deg):
+            points3D = np.hstack([points3D, point3D])
+        else:
+            new_landmarks[idx] = False
+    return new_landmarks, points3D

@@ -581,6 +581,35 @@ def test_filter_candidates_device_resident_after_tracking(fe):
     assert np.array_equal(d_c[:m].cpu().numpy().T, rc)
 
 
+def test_triangulate_candidates_against_restated_loop(fe):
+    """vofe_triangulate_candidates vs the reference's loop with a LAPACK SVD in place of cv2.triangulatePoints
+    (cv2 is absent: this row is tolerance-pinned, not bit-pinned).  3D points agree to SVD rounding error; the
+    keep/drop decisions are identical for every candidate whose decision does not hang on that rounding."""
+    from test_oracle_cpu import triangulation_scene
+    total = 0
+    for n, seed, fdt in ((1, 1, np.float32), (200, 2, np.float32), (1500, 3, np.float64), (64, 5, np.float32)):
+        K, pose, Ci, Fi, Ti, flags = triangulation_scene(n, seed, fdt)
+        margins = []
+        with np.errstate(all="ignore"):
+            rkeep, rpts = oracle.triangulate_candidates(K, pose, Ci, Fi, Ti, flags, margins=margins)
+        keep, pts = fe.triangulate_candidates(K, pose, Ci, Fi, Ti, flags)
+        assert keep.dtype == bool and keep.shape == rkeep.shape and pts.dtype == np.float64 and pts.shape[0] == 3
+        shaky = np.zeros(n, bool)
+        for idx, depth_margin, angle_margin in margins:
+            shaky[idx] = not (abs(depth_margin) > 1e-3 and abs(angle_margin) > 1e-5)
+        assert np.array_equal(keep[~shaky], rkeep[~shaky]) and shaky.sum() <= max(2, n // 50)
+        assert not (keep & ~flags).any()
+        both = keep & rkeep
+        a = pts[:, np.cumsum(keep)[both] - 1]
+        b = rpts[:, np.cumsum(rkeep)[both] - 1]
+        tol = 2e-3 if fdt == np.float32 else 1e-7           # float32 points4D: 1 ulp of a homogeneous coordinate
+        assert np.allclose(a, b, rtol=tol, atol=tol * 10), np.abs(a - b).max()
+        total += int(both.sum())
+    assert total > 300
+    none, empty = fe.triangulate_candidates(K, pose, Ci, Fi, Ti, np.zeros(Ci.shape[1], bool))
+    assert not none.any() and empty.shape == (3, 0)
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -378,3 +378,54 @@ def test_gftt_candidate_rule_pinned_by_scipy_ndimage():
         got = oracle.goodFeaturesToTrack(img, 0, 0.01, 0).reshape(-1, 2)
         assert got.shape == ref.shape and np.array_equal(got, ref)
         assert len(ref) > 50
+
+
+# ------------------------------------------------------------------ batched triangulation
+def triangulation_scene(n, seed, fdt=np.float32, noise=0.3):
+    """A two-view scene: world points in front of both cameras, first view at a random earlier pose per candidate,
+    pixel noise on both observations, some points behind the camera / with a tiny baseline."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.2], [0, 0, 1.0]])
+
+    def pose_at(tz, yaw, tx):
+        c, s = np.cos(yaw), np.sin(yaw)
+        T = np.eye(4)
+        T[:3, :3] = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+        T[:3, 3] = [tx, 0.02 * tz, tz]
+        return T                                         # camera-to-world, as the reference stores poses
+
+    cur = pose_at(6.0, 0.05, 0.3)
+    X = np.vstack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(10, 60, n)])
+    Ci, Fi, Ti = np.empty((2, n), np.float32), np.empty((2, n), fdt), np.empty((12, n))
+    for i in range(n):
+        first = pose_at(rng.uniform(0, 5.9), rng.uniform(-0.05, 0.05), rng.uniform(-0.5, 0.5))
+        if i % 11 == 0:
+            first = pose_at(5.999, 0.05, 0.3)            # almost no baseline: fails the angle test
+        for T, out in ((first, Fi), (cur, Ci)):
+            pc = np.linalg.inv(T) @ np.append(X[:, i], 1.0)
+            uv = (K @ pc[:3])[:2] / pc[2] + rng.normal(0, noise, 2)
+            out[:, i] = uv
+        Ti[:, i] = first[:3, :].reshape(-1)
+    if n > 7:
+        Ci[:, 7] = Fi[:, 7][::-1] * 0.5                  # inconsistent observation: triangulates behind or far off
+    flags = rng.random(n) < 0.85
+    return K, cur[:3, :], Ci, Fi, Ti, flags
+
+
+def test_triangulation_restatement_recovers_known_points():
+    """The restated loop (continuous.py:450-485) on a noise-free scene returns the world points themselves; the
+    stand-in for cv2.triangulatePoints is checked against an independent least-squares DLT solve."""
+    K, pose, Ci, Fi, Ti, flags = triangulation_scene(60, 4, np.float64, noise=0.0)
+    Ci64 = Ci.astype(np.float64)
+    P2 = K @ oracle._invert_transformation(pose)
+    for i in (1, 2, 3, 5, 13, 20, 31, 47):               # consistent observations with a real baseline
+        P1 = K @ oracle._invert_transformation(Ti[:, i].reshape(3, 4))
+        X4 = oracle._triangulate_points(P1, P2, Fi[:, i], Ci64[:, i])
+        Xh = (X4[:3] / X4[3]).ravel()
+        for P, uv in ((P1, Fi[:, i]), (P2, Ci64[:, i])):
+            pr = P @ np.append(Xh, 1.0)
+            assert np.allclose(pr[:2] / pr[2], uv, atol=2e-2)            # Ci was rounded to float32 pixels
+    keep, pts = oracle.triangulate_candidates(K, pose, Ci, Fi, Ti, flags)
+    assert pts.shape == (3, int(keep.sum())) and keep.sum() > 10 and not keep[::11].any() and not (keep & ~flags).any()
+    none, empty = oracle.triangulate_candidates(K, pose, Ci, Fi, Ti, np.zeros(60, bool))
+    assert not none.any() and empty.shape == (3, 0)

@@ -362,4 +362,22 @@ int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_
     return VOFE_OK;
 }
 
+int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy,
+                                const void* d_first_xy, int first_is_f64, const double* d_transform,
+                                int transform_dim, const uint8_t* d_flag_in, int n, double alpha_min,
+                                uint8_t* d_flag_out, double* d_xyz) {
+    if (!ctx) { vofe_set_error("vofe_triangulate_candidates: ctx is NULL"); return VOFE_E_ARG; }
+    if (n < 0) { vofe_set_error("vofe_triangulate_candidates: negative count"); return VOFE_E_ARG; }
+    if (transform_dim < 12 || transform_dim > 16) {
+        vofe_set_error("vofe_triangulate_candidates: transform_dim must be 12..16 (a 3x4 pose per candidate), got %d", transform_dim);
+        return VOFE_E_ARG;
+    }
+    if (!d_K || !d_pose || (n > 0 && (!d_cur_xy || !d_first_xy || !d_transform || !d_flag_in || !d_flag_out || !d_xyz))) {
+        vofe_set_error("vofe_triangulate_candidates: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    return vofe_launch_triangulate(ctx, d_K, d_pose, d_cur_xy, d_first_xy, first_is_f64, d_transform, transform_dim, d_flag_in, n,
+                                   alpha_min, d_flag_out, d_xyz);
+}
+
 }  // extern "C"

@@ -106,6 +106,117 @@ __global__ __launch_bounds__(1024) void candidate_filter_kernel(const float2* cu
     if (threadIdx.x == 0) *count_out = base;
 }
 
+
+// ---- batched triangulation of matured candidates (reference continuous.py:450-485, 274-309) ---------------------
+//     for idx with new_landmarks[idx]:
+//         proj1 = K @ inv(Ti[:, idx].reshape(3, 4));  proj2 = K @ inv(pose)
+//         X4 = cv2.triangulatePoints(proj1, proj2, Fi[:, idx], Ci[:, idx]);  X = X4[:3] / X4[3]
+//         if X[2] < -t_idx[2]: drop        (t_idx = Ti[:3, 3] of that candidate)
+//         alpha = arccos(clip(dot(unit(X - t_cur), unit(X - t_idx)), -1, 1));  keep iff |alpha| > alpha_min
+// One thread per candidate, float64 throughout.  cv::triangulatePoints builds the 4x4 DLT matrix
+// (x * P[2] - P[0], y * P[2] - P[1] per view) and takes the right singular vector of its smallest singular value
+// from a one-sided Jacobi SVD; the same construction and the same kind of SVD run here, and the result is rounded
+// to the type of the first-observation points (float32 / float64) exactly where OpenCV stores points4D in that
+// type.  Rotation order and stopping differ from OpenCV's implementation, so this stage agrees with cv2 to
+// rounding error of the SVD, not bit for bit ("parity unpinned" for this row; everything after X is the
+// reference's own float64 numpy arithmetic, evaluated in the same order).
+__device__ void invert_rt(const double* T, double* out) {        // T, out: 3x4 row-major; out = [R^T | -R^T t]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[i * 4 + j] = T[j * 4 + i];
+        out[i * 4 + 3] = (-T[0 * 4 + i]) * T[3] + (-T[1 * 4 + i]) * T[7] + (-T[2 * 4 + i]) * T[11];
+    }
+}
+__device__ void k_times(const double* K, const double* M, double* P) {   // P (3x4) = K (3x3) @ M (3x4)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[i * 4 + j] = K[i * 3 + 0] * M[0 * 4 + j] + K[i * 3 + 1] * M[1 * 4 + j] + K[i * 3 + 2] * M[2 * 4 + j];
+}
+
+template <typename F>
+__global__ __launch_bounds__(64) void triangulate_kernel(const double* __restrict__ Kmat, const double* __restrict__ pose,
+                                                         const float2* __restrict__ cur, const F* __restrict__ first,
+                                                         const double* __restrict__ transform, int tdim,
+                                                         const uint8_t* __restrict__ flag_in, int n, double alpha_min,
+                                                         uint8_t* __restrict__ flag_out, double* __restrict__ xyz) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (!flag_in[i]) { flag_out[i] = 0; return; }
+    double K[9], T2[12], T1[12], M[12], P1[12], P2[12];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { T2[k] = pose[k]; T1[k] = transform[(size_t)i * tdim + k]; }
+    invert_rt(T1, M); k_times(K, M, P1);
+    invert_rt(T2, M); k_times(K, M, P2);
+    const double x1 = (double)first[2 * (size_t)i], y1 = (double)first[2 * (size_t)i + 1];
+    const double x2 = (double)cur[i].x, y2 = (double)cur[i].y;
+    // A (4x4): columns are orthogonalised in place (one-sided Jacobi), V accumulates the rotations
+    double A[4][4], V[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0][k] = x1 * P1[8 + k] - P1[k];
+        A[1][k] = y1 * P1[8 + k] - P1[4 + k];
+        A[2][k] = x2 * P2[8 + k] - P2[k];
+        A[3][k] = y2 * P2[8 + k] - P2[4 + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[k][j] = (k == j) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool changed = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double a = 0, b = 0, c = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a += A[r][p] * A[r][p]; b += A[r][q] * A[r][q]; c += A[r][p] * A[r][q]; }
+                if (fabs(c) <= 2.220446049250313e-16 * sqrt(a * b)) continue;
+                changed = true;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double ap = A[r][p], aq = A[r][q];
+                    A[r][p] = cs * ap - sn * aq; A[r][q] = sn * ap + cs * aq;
+                    const double vp = V[r][p], vq = V[r][q];
+                    V[r][p] = cs * vp - sn * vq; V[r][q] = sn * vp + cs * vq;
+                }
+            }
+        if (!changed) break;
+    }
+    int best = 0;
+    double bn = INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double nn = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nn += A[r][c] * A[r][c];
+        if (nn < bn) { bn = nn; best = c; }
+    }
+    double v4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v4[r] = best == 0 ? V[r][0] : (best == 1 ? V[r][1] : (best == 2 ? V[r][2] : V[r][3]));
+    // points4D is stored in the point type, the division happens in that type (point4D_hom[:3] / point4D_hom[3])
+    const F h0 = (F)v4[0], h1 = (F)v4[1], h2 = (F)v4[2], h3 = (F)v4[3];
+    const double X = (double)(h0 / h3), Y = (double)(h1 / h3), Z = (double)(h2 / h3);
+    xyz[3 * (size_t)i] = X; xyz[3 * (size_t)i + 1] = Y; xyz[3 * (size_t)i + 2] = Z;
+    bool keep = !(Z < -T1[11]);
+    if (keep) {
+        double c0 = X - T2[3], c1 = Y - T2[7], c2 = Z - T2[11];
+        double f0 = X - T1[3], f1 = Y - T1[7], f2 = Z - T1[11];
+        const double nc = sqrt(c0 * c0 + c1 * c1 + c2 * c2), nf = sqrt(f0 * f0 + f1 * f1 + f2 * f2);
+        c0 /= nc; c1 /= nc; c2 /= nc; f0 /= nf; f1 /= nf; f2 /= nf;
+        double d = c0 * f0 + c1 * f1 + c2 * f2;
+        d = d < -1.0 ? -1.0 : (d > 1.0 ? 1.0 : d);           // np.clip; a NaN stays NaN and fails the test below
+        keep = fabs(acos(d)) > alpha_min;
+    }
+    flag_out[i] = keep ? 1 : 0;
+}
+
 }  // namespace
 
 // smallest x >= 0 with sqrt(x) > t (host sqrt is correctly rounded); NaN when no distance can pass
@@ -171,5 +282,21 @@ int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int 
                        reinterpret_cast<const float2*>(d_existing_xy), n_existing, s_star, d_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "new_feature_mask launch");
+    return VOFE_OK;
+}
+
+int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy, const void* d_first_xy,
+                            int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in, int n,
+                            double alpha_min, uint8_t* d_flag_out, double* d_xyz) {
+    if (n == 0) return VOFE_OK;
+    const dim3 grid((n + 63) / 64), block(64);
+    if (first_is_f64)
+        hipLaunchKernelGGL(triangulate_kernel<double>, grid, block, 0, ctx->stream, d_K, d_pose, reinterpret_cast<const float2*>(d_cur_xy),
+                           static_cast<const double*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
+    else
+        hipLaunchKernelGGL(triangulate_kernel<float>, grid, block, 0, ctx->stream, d_K, d_pose, reinterpret_cast<const float2*>(d_cur_xy),
+                           static_cast<const float*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vofe_hip_fail(e, "triangulate launch");
     return VOFE_OK;
 }

@@ -66,6 +66,9 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
                                  int first_is_f64, const double* d_transform, int tdim, int n, double dist_min,
                                  double dist_max, double dist_tri, float* d_tracked_out, void* d_first_out,
                                  double* d_transform_out, uint8_t* d_tri_out, int* d_count_out);
+int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy, const void* d_first_xy,
+                            int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in, int n,
+                            double alpha_min, uint8_t* d_flag_out, double* d_xyz);
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,

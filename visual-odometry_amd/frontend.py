@@ -311,6 +311,38 @@ class FrontEnd:
             cnt.data_ptr(), C.byref(m)))
         return m.value
 
+    def triangulate_candidates(self, K, pose, Ci, Fi, Ti, new_landmarks, alpha_deg=1):
+        """continuous.py:450-485 in one launch: triangulate every candidate flagged in `new_landmarks` between its first
+        observation (Fi, pose Ti[:, idx]) and the current frame (Ci, `pose` 3x4 or 4x4), drop points with negative depth
+        or a baseline angle of at most alpha_deg degrees.  Returns (new_landmarks (M,) bool as the reference leaves it,
+        points3D (3,P) float64 of the kept candidates in order)."""
+        c = np.asarray(Ci)
+        f = np.asarray(Fi)
+        t = np.asarray(Ti)
+        flags = np.asarray(new_landmarks).reshape(-1)
+        if c.dtype != np.float32 or f.dtype not in (np.float32, np.float64):
+            raise error(-1, "Ci must be float32 and Fi float32 or float64")
+        if c.ndim != 2 or c.shape[0] != 2 or f.shape != c.shape or t.ndim != 2 or t.shape[1] != c.shape[1] or \
+                flags.shape[0] != c.shape[1] or not 12 <= t.shape[0] <= 16:
+            raise error(-1, "expected Ci (2,M), Fi (2,M), Ti (12..16,M), new_landmarks (M,)")
+        m = c.shape[1]
+        if m == 0 or not flags.any():
+            return flags.astype(bool), np.empty((3, 0))
+        dev = self.device
+        d_K = torch.from_numpy(np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))).to(dev)
+        d_pose = torch.from_numpy(np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4])).to(dev)
+        d_c = torch.from_numpy(np.ascontiguousarray(c.T)).to(dev)
+        d_f = torch.from_numpy(np.ascontiguousarray(f.T)).to(dev)
+        d_t = torch.from_numpy(np.ascontiguousarray(t.T, dtype=np.float64)).to(dev)
+        d_in = torch.from_numpy(np.ascontiguousarray(flags != 0).view(np.uint8)).to(dev)
+        d_out = torch.empty(m, dtype=torch.uint8, device=dev)
+        d_xyz = torch.empty((m, 3), dtype=torch.float64, device=dev)
+        _lib.check(self.L.vofe_triangulate_candidates(
+            self.ctx, d_K.data_ptr(), d_pose.data_ptr(), d_c.data_ptr(), d_f.data_ptr(), int(f.dtype == np.float64),
+            d_t.data_ptr(), t.shape[0], d_in.data_ptr(), m, float(np.deg2rad(alpha_deg)), d_out.data_ptr(), d_xyz.data_ptr()))
+        keep = d_out.cpu().numpy().astype(bool)
+        return keep, d_xyz.cpu().numpy()[keep].T
+
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):
         """images: CUDA uint8 (B,H,W).  Returns (corners CUDA f32 (B,maxCorners,2), counts list)."""
