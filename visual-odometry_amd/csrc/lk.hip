@@ -125,6 +125,11 @@ __device__ __forceinline__ uint2 gload_u64(gbase_t b, unsigned off) {
 }
 __device__ __forceinline__ unsigned gload_u16(gbase_t b, unsigned off) { return *((const VOFE_GLOBAL u16_unaligned*)(b + off)); }
 __device__ __forceinline__ unsigned gload_u8(gbase_t b, unsigned off) { return *(b + off); }
+// 12 bytes in one load: the 8 staged pixels of a task plus the ninth byte its last pair needs (x = lo, y = hi,
+// z = next dword; bytes 9..11 are read and ignored: they lie in the plane's padding at worst)
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 __attribute__((aligned(1))) u32x3_unaligned;
+__device__ __forceinline__ u32x3 gload_u96(gbase_t b, unsigned off) { return *((const VOFE_GLOBAL u32x3_unaligned*)(b + off)); }
 
 // Diagnostic build only (-DLK_STAMPS): s_memtime deltas per phase, written to counters[8 + 8*block + k]
 // for the first 256 blocks.  Never enabled in the shipped library.
@@ -161,8 +166,9 @@ __device__ __forceinline__ void stage_load(StageRegs& s, const uint8_t* __restri
         if (t < tasks) {
             const int gy = min(max(ry0 + row, ymin), ymax);
             const unsigned off = (unsigned)((gy - ymin) * B.pitch + seg * 8);
-            s.v[k] = gload_u64(base, off);
-            s.nb[k] = gload_u8(base, off + 8u);
+            const u32x3 q = gload_u96(base, off);
+            s.v[k] = make_uint2(q.x, q.y);
+            s.nb[k] = q.z;
         }
     }
 }
@@ -510,8 +516,9 @@ __device__ __forceinline__ void stage_load(Stage<PPW>& s, gbase_t Jb, unsigned s
         if (t < TASKS) {
             const int gy = min(max(ry0 + row, ymin), ymax);
             const unsigned off = slot_off + (unsigned)((gy + W) * B.pitch + (rx0 + PADX + seg * 8));
-            s.v[k] = gload_u64(Jb, off);
-            s.nb[k] = gload_u8(Jb, off + 8u);
+            const u32x3 q = gload_u96(Jb, off);
+            s.v[k] = make_uint2(q.x, q.y);
+            s.nb[k] = q.z;
         }
     }
 }
