@@ -290,3 +290,47 @@ def triangulate_candidates(K, pose, Ci, Fi, Ti, new_landmarks, alpha_deg=1, marg
         else:
             new_landmarks[idx] = False
     return new_landmarks, points3D
+
+
+def handle_candidates(K, img_current, img_prev, Ci, Fi, Ti, Pi, Xi, pose, max_corners=1000, quality_level=0.01,
+                      min_distance=10, lk_params=None, threshold_new_keypoints=15, threshold_triangulation=15,
+                      threshold_candidates_min=2, threshold_candidates_max=100, threshold_alpha_deg=1):
+    """Reference ContinuousVO._handle_candidates (continuous.py:375-495) line by line, with the oracle's restatements
+    where the reference calls cv2 (goodFeaturesToTrack, calcOpticalFlowPyrLK inside _track_keypoints,
+    triangulatePoints) and scipy's own cdist where it calls cdist."""
+    from scipy.spatial.distance import cdist
+    features_current = goodFeaturesToTrack(img_current, maxCorners=max_corners, qualityLevel=quality_level,
+                                           minDistance=min_distance)
+    features_current = np.float32(features_current).reshape(-1, 2)
+    tracked_features, status, _ = track_keypoints(Ci, img_prev, img_current, **(lk_params or {}))
+    valid_idx = np.where(status == 1)[0]
+    Ci = tracked_features[:, valid_idx]
+    Fi = Fi[:, valid_idx]
+    Ti = Ti[:, valid_idx]
+    distances = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0))
+    good_candidates = (distances > threshold_candidates_min) & (distances < threshold_candidates_max)
+    Ci = Ci[:, good_candidates]
+    Fi = Fi[:, good_candidates]
+    Ti = Ti[:, good_candidates]
+    existing_features = np.vstack([Ci.T, Pi.T])
+    distance_matrix = cdist(features_current, existing_features)
+    min_distances = np.min(distance_matrix, axis=1)
+    new_feature_mask = min_distances > threshold_new_keypoints
+    new_features = features_current[new_feature_mask].T
+    distance_matrix = np.sqrt(np.sum((Ci - Fi) ** 2, axis=0))
+    new_landmarks = distance_matrix > threshold_triangulation
+    if new_landmarks.sum() > 0:
+        new_landmarks, points3D = triangulate_candidates(K, pose, Ci, Fi, Ti, new_landmarks, threshold_alpha_deg)
+        Pi = np.hstack([Pi, Ci[:, new_landmarks]])
+        Xi = np.hstack([Xi, points3D])
+        no_new_landmark = np.where(new_landmarks == 0)[0]
+        Ci = Ci[:, no_new_landmark]
+        Fi = Fi[:, no_new_landmark]
+        Ti = Ti[:, no_new_landmark]
+    if new_features.size > 0:
+        pose = np.asarray(pose)[:3, :].reshape((-1, 1))
+        tiled_pose = np.tile(pose, (1, new_features.shape[1]))
+        Ci = np.hstack([Ci, new_features])
+        Fi = np.hstack([Fi, new_features])
+        Ti = np.hstack([Ti, tiled_pose])
+    return Pi, Xi, Ci, Fi, Ti

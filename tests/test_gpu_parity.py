@@ -610,6 +610,41 @@ def test_triangulate_candidates_against_restated_loop(fe):
     assert not none.any() and empty.shape == (3, 0)
 
 
+def test_handle_candidates_follows_the_reference_method_over_a_sequence(fe):
+    """FrontEnd.handle_candidates (every stage on the device) against the line-by-line restatement of
+    ContinuousVO._handle_candidates (continuous.py:375-495) over six frames: both get the same previous state each
+    frame; landmark / candidate arrays must come out identical, triangulated points to SVD rounding."""
+    frames = _seq(376, 1241, 3, 7)
+    K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.2], [0, 0, 1.0]])
+
+    def pose_at(t):
+        T = np.eye(4)
+        T[:3, 3] = [0.02 * t, 0.0, 0.6 * t]
+        return T
+
+    first = oracle.goodFeaturesToTrack(frames[0], 600, 0.01, 10).reshape(-1, 2)
+    Ci = first.T.copy()                                           # (2,M) float32
+    Fi = first.T.astype(np.float64)                               # the initial state is float64 in the reference
+    Ti = np.tile(pose_at(0)[:3, :].reshape(-1, 1), (1, Ci.shape[1]))
+    Pi = np.empty((2, 0), np.float32)
+    Xi = np.empty((3, 0))
+    promoted = grown = 0
+    for t in range(1, 7):
+        pose = pose_at(t)
+        args = (K, frames[t], frames[t - 1], Ci, Fi, Ti, Pi, Xi, pose)
+        kw = dict(max_corners=600, quality_level=0.01, min_distance=10, threshold_alpha_deg=0.05)
+        with np.errstate(all="ignore"):
+            rPi, rXi, rCi, rFi, rTi = oracle.handle_candidates(*args, **kw)
+        gPi, gXi, gCi, gFi, gTi = fe.handle_candidates(*args, **kw)
+        for name, g, r in (("Pi", gPi, rPi), ("Ci", gCi, rCi), ("Fi", gFi, rFi), ("Ti", gTi, rTi)):
+            assert g.shape == r.shape and g.dtype == r.dtype and np.array_equal(g, r), (t, name, g.shape, r.shape)
+        assert gXi.shape == rXi.shape and gXi.dtype == rXi.dtype and np.allclose(gXi, rXi, rtol=1e-6, atol=1e-6), t
+        promoted += rPi.shape[1] - Pi.shape[1]
+        grown += int(rCi.shape[1] > 0)
+        Pi, Xi, Ci, Fi, Ti = rPi, rXi, rCi, rFi, rTi
+    assert promoted > 0 and grown == 6 and Ci.shape[1] > 100
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -265,6 +265,9 @@ class FrontEnd:
         f = np.asarray(Fi)
         t = np.asarray(Ti)
         st = np.asarray(status).reshape(-1)
+        if c.size == 0 and c.ndim == 2 and f.ndim == 2 and t.ndim == 2:
+            # no candidates (track_keypoints returns its float64 (2,0) array then): nothing to launch
+            return c[:, :0], f[:, :0], t[:, :0], np.zeros(0, dtype=bool)
         if c.dtype != np.float32:
             raise error(-1, "tracked_features must be the float32 output of track_keypoints")
         if f.dtype not in (np.float32, np.float64):
@@ -342,6 +345,39 @@ class FrontEnd:
             d_t.data_ptr(), t.shape[0], d_in.data_ptr(), m, float(np.deg2rad(alpha_deg)), d_out.data_ptr(), d_xyz.data_ptr()))
         keep = d_out.cpu().numpy().astype(bool)
         return keep, d_xyz.cpu().numpy()[keep].T
+
+    def handle_candidates(self, K, img_current, img_prev, Ci, Fi, Ti, Pi, Xi, pose, max_corners=1000, quality_level=0.01,
+                          min_distance=10, lk_params=None, threshold_new_keypoints=15, threshold_triangulation=15,
+                          threshold_candidates_min=2, threshold_candidates_max=100, threshold_alpha_deg=1):
+        """ContinuousVO._handle_candidates (continuous.py:375-495) with every stage on the device: detection, candidate
+        tracking, status compaction + travel-distance band, new-feature de-duplication, triangulation of matured
+        candidates, and the reference's own numpy bookkeeping around them.  Ci/Fi/Ti are the candidate arrays of the
+        previous FrameState, Pi/Xi the landmarks that survived pose estimation, `pose` the current 3x4 or 4x4 pose.
+        Returns (Pi, Xi, Ci, Fi, Ti) as the reference does."""
+        features_current = self.goodFeaturesToTrack(img_current, maxCorners=max_corners, qualityLevel=quality_level,
+                                                    minDistance=min_distance)
+        features_current = np.float32(features_current).reshape(-1, 2)               # continuous.py:386
+        tracked_features, status, _ = self.track_keypoints(Ci, img_prev, img_current, **(lk_params or {}))
+        Ci, Fi, Ti, new_landmarks = self.filter_candidates(tracked_features, status, Fi, Ti, threshold_candidates_min,
+                                                           threshold_candidates_max, threshold_triangulation)
+        existing_features = np.vstack([Ci.T, Pi.T])                                  # continuous.py:408
+        new_features = features_current[self.new_feature_mask(features_current, existing_features,
+                                                              threshold_new_keypoints)].T
+        if new_landmarks.sum() > 0:                                                  # continuous.py:450-485
+            new_landmarks, points3D = self.triangulate_candidates(K, pose, Ci, Fi, Ti, new_landmarks, threshold_alpha_deg)
+            Pi = np.hstack([Pi, Ci[:, new_landmarks]])
+            Xi = np.hstack([Xi, points3D])
+            no_new_landmark = np.where(new_landmarks == 0)[0]
+            Ci = Ci[:, no_new_landmark]
+            Fi = Fi[:, no_new_landmark]
+            Ti = Ti[:, no_new_landmark]
+        if new_features.size > 0:                                                    # continuous.py:487-493
+            pose_col = np.asarray(pose)[:3, :].reshape((-1, 1))
+            tiled_pose = np.tile(pose_col, (1, new_features.shape[1]))
+            Ci = np.hstack([Ci, new_features])
+            Fi = np.hstack([Fi, new_features])
+            Ti = np.hstack([Ti, tiled_pose])
+        return Pi, Xi, Ci, Fi, Ti
 
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):
