@@ -39,7 +39,7 @@ N_FRAMES = 8
 # (pairs per launch, points per pair).  The kernel's loads are narrow (2- and 8-byte gathers), a pattern for
 # which the guide gives no gfx950 FETCH_SIZE correction, so the raw value is reported; it is well below the
 # algorithmic bytes because the patches are served from L2 / MALL.
-LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((432824.2 + 1801.1) * 1024), (1, 2000): int((18062.4 + 142.7) * 1024)}
+LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((433516.4 + 1810.0) * 1024), (1, 2000): int((18081.0 + 142.9) * 1024)}
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
