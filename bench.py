@@ -268,9 +268,9 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "point_levels_per_launch": float(cnt_launch[1]),
                 "gn_iterations_per_launch": float(cnt_launch[2]),
-                "valu_cycles_per_instruction": 4.05,
+                "valu_cycles_per_instruction": 4.27,
                 "valu_note": "profiles/r01_pmc_lk_valu.txt + r01_ubench_valu_rates.txt: the launch issues one VALU instruction per "
-                             "4.05 cycles per SIMD for its whole duration; the instructions that dominate it (v_dot2c, v_mul_i32_i24, "
+                             "4.27 cycles per SIMD for its whole duration; the instructions that dominate it (v_dot2, v_mul_i32_i24, "
                              "v_add3, DPP adds) measure 4.1-4.2 cycles each in isolation, plain 2-operand ops 2.4",
                 "note": "VALU-issue bound, not HBM (DESIGN.md 4/5): patches are L2/MALL resident, so the HBM fraction is "
                         "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2; traffic = PMC FETCH_SIZE + "
