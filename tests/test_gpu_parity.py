@@ -735,9 +735,10 @@ def test_real_stereo_pair_tracking(fe):
 def test_randomised_lk_sweep_all_window_shapes(fe):
     """40 random (image size, window, levels, criteria, flags) combinations: every row-group template of the
     run-time-geometry kernel (windows 3..64 wide, 3..64 tall) against the oracle, bit for bit."""
-    rng = np.random.default_rng(2024)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 2024)))       # soak runs: other seeds, more cases
     seen_r = set()
-    for case in range(40):
+    for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40))):
         h, w = int(rng.integers(48, 260)), int(rng.integers(48, 320))
         ww, wh = int(rng.integers(3, 65)), int(rng.integers(3, 65))
         if case < 10:                                   # make sure the extremes are in
@@ -758,10 +759,44 @@ def test_randomised_lk_sweep_all_window_shapes(fe):
     assert len(seen_r) >= 12
 
 
+def test_randomised_lk_21x21_sweep_all_kernels(fe, monkeypatch):
+    """Random frames, point sets (interior, border, far outside, NaN), criteria and flags through the three 21x21
+    kernels (one, two and four keypoints per wavefront) and the tracker glue: identical to the oracle, bit for bit."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 4242)))
+    for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40)) // 2):
+        h, w = int(rng.integers(40, 300)), int(rng.integers(40, 420))
+        lvl = int(rng.integers(0, 5))
+        a, b = _seq(h, w, 900 + case)
+        n = int(rng.integers(1, 400))
+        pts = np.concatenate([(rng.random((n, 2)) * [w - 1, h - 1]), rng.normal(0, 25, (8, 2)) + [[0, 0], [w, h], [w, 0], [0, h]] * 2])
+        pts = pts.astype(np.float32)
+        if case % 9 == 0:
+            pts[0] = [np.nan, 5]
+            pts[-1] = [1e9, -1e9]
+        crit = [(3, 30, 0.01), (1, 3, 0.0), (2, 0, 0.03), (3, 50, 1e-4)][case % 4]
+        flags = [0, 0, 4, 8][case % 4]
+        init = (pts + rng.normal(0, 2.0, pts.shape)).astype(np.float32) if flags & 4 else None
+        mineig = [1e-4, 1e-3, 5e-3][case % 3]
+        with np.errstate(all="ignore"):
+            n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig, nthreads=8)
+            t0 = oracle.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig, 1.0, 8)
+        for kern in ("x1", "x2", "x4"):
+            monkeypatch.setenv("VOFE_LK", kern)
+            n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig)
+            assert np.array_equal(s0, s1), (case, kern, h, w, lvl)
+            assert np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True), (case, kern, h, w, lvl)
+            t1 = fe.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig)
+            for x, y in zip(t0, t1):
+                assert np.array_equal(x, y, equal_nan=True), (case, kern, "fb")
+        monkeypatch.delenv("VOFE_LK")
+
+
 def test_randomised_gftt_sweep(fe):
     """40 random detector configurations (size, quality, minDistance incl. 0 and large, maxCorners, mask, Harris)."""
-    rng = np.random.default_rng(77)
-    for case in range(40):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 77)))
+    for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40))):
         h, w = int(rng.integers(20, 300)), int(rng.integers(20, 400))
         a = _seq(h, w, 500 + case, 1)[0]
         if case % 7 == 0:
