@@ -474,6 +474,29 @@ def test_sequence_tracker_matches_per_call_path(fe):
         SequenceTracker(H, W, frontend=fe).track(frames[0], land)
 
 
+def test_sequence_tracker_overlapped_track_and_detect(fe):
+    """track_and_detect runs the detector on a second context/stream while the tracker works: same triples and the same
+    corner list as track() followed by detect(), frame after frame (also after a prefetch)."""
+    from visual_odometry_amd import SequenceTracker
+    frames = _seq(376, 1241, 21, 5)
+    pts = oracle.goodFeaturesToTrack(frames[0], 800, 0.01, 7).reshape(-1, 2).T
+    a = SequenceTracker(376, 1241, frontend=fe)
+    b = SequenceTracker(376, 1241, frontend=fe)
+    a.reset(frames[0]); b.reset(frames[0])
+    cur = pts
+    for t in range(1, 5):
+        if t == 3:
+            b.prefetch(frames[t])
+        ref = a.track(frames[t], cur, cur[:, :50], np.empty((2, 0)))
+        ref_c = a.detect(500, 0.01, 10)
+        got, got_c = b.track_and_detect(frames[t], (cur, cur[:, :50], np.empty((2, 0))), 500, 0.01, 10)
+        assert len(got) == 3 and np.array_equal(got_c, ref_c) and np.array_equal(ref_c, oracle.goodFeaturesToTrack(frames[t], 500, 0.01, 10))
+        for (x0, s0, e0), (x1, s1, e1) in zip(ref, got):
+            assert np.array_equal(x0, x1) and np.array_equal(s0, s1) and np.array_equal(e0, e1)
+        cur = ref[0][0][:, ref[0][1] == 1]
+    a.close(); b.close()
+
+
 # ------------------------------------------------------------------ BASELINE.json full-size configurations
 @pytest.mark.parametrize("cfg,md", [("malaga", 10), ("stress", 10)])
 def test_full_size_config_front_end_frame(fe, cfg, md):

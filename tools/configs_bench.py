@@ -73,6 +73,11 @@ def front_end_frame(fe, cfg, md, reps):
         trk.track(fr[k[0] % 3], pts.T)
         trk.detect(n, 0.01, md)
     t_host = timed(host, max(3, reps // 4))
+
+    def host_overlapped():
+        k[0] += 1
+        trk.track_and_detect(fr[k[0] % 3], (pts.T,), n, 0.01, md)
+    t_host_ov = timed(host_overlapped, max(3, reps // 4))
     trk.close()
     return {"config": cfg, "frame": "%dx%d, %d points, win %dx%d, %d levels, GFTT maxCorners %d minDistance %d" %
             (W, H, n, win[0], win[1], lvl + 1, n, md),
@@ -80,6 +85,7 @@ def front_end_frame(fe, cfg, md, reps):
             "front_end_frame_us_cached_pyramid": round(t_cached * 1e6, 1),
             "lk_frame_us": round(t_lk * 1e6, 1),
             "front_end_frame_us_host_numpy_in_out_cached": round(t_host * 1e6, 1),
+            "front_end_frame_us_host_numpy_in_out_detector_overlapped": round(t_host_ov * 1e6, 1),
             "frames_per_s_cached": round(1 / t_cached, 1), "tracked_of_attempted": [tracked, n]}
 
 

@@ -90,13 +90,15 @@ class Pyramid:
 class FrontEnd:
     """One context = one GPU + one stream (the current torch stream of `device` at construction)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
         self.L = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("visual-odometry_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.current_stream(self.device)
+        # `stream`: a torch.cuda.Stream to bind the context to (e.g. a side stream so that detection overlaps
+        # tracking); callers then issue their torch work for this context under `torch.cuda.stream(stream)`
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         self.ctx = C.c_void_p()
         _lib.check(self.L.vofe_create(int(device), C.c_void_p(self.stream.cuda_stream), C.byref(self.ctx)))
         self._pyr_cache = {}

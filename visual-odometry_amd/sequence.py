@@ -31,6 +31,7 @@ class SequenceTracker:
         self.frame_index = -1                     # index of the frame held in slot frame_index & 1
         self._img = [None, None]                  # device images of the two slots (for detect())
         self._stage, self._stage_k, self._copy_stream, self._prefetched = None, 0, None, None
+        self._det_fe, self._det_stream = None, None            # side context for track_and_detect()
 
     # -- frames ----------------------------------------------------------------------------------
     def prefetch(self, img_next):
@@ -57,8 +58,11 @@ class SequenceTracker:
         if pre is not None and pre[0] is img:
             torch.cuda.current_stream(self.fe.device).wait_event(pre[2])
             d = pre[1]
+            self._uploaded = pre[2]
         else:
             d = self.fe.to_device(img)
+            self._uploaded = torch.cuda.Event()                # the frame is resident once this has passed
+            self._uploaded.record(torch.cuda.current_stream(self.fe.device))
         if tuple(d.shape) != (self.h, self.w):
             raise error(-1, "frame size %s does not match the tracker geometry %s" % (tuple(d.shape), (self.h, self.w)))
         self.frame_index += 1
@@ -78,6 +82,9 @@ class SequenceTracker:
         Returns one (tracked (2,N) f32, status (N,) u8, err (N,) f32) triple per set, identical to
         track_keypoints(points, img_prev, img_current); empty sets give the empty triple of
         continuous.py:131-132.  img_current becomes the previous frame of the next call."""
+        return self._collect(self._launch(img_current, point_sets))
+
+    def _launch(self, img_current, point_sets):
         if self.frame_index < 0:
             raise error(-1, "SequenceTracker.track before reset()")
         prev_slot = self.frame_index & 1
@@ -85,6 +92,7 @@ class SequenceTracker:
         sets = [np.asarray(p) for p in point_sets]
         flat = [np.ascontiguousarray(p.T.reshape(-1, 2).astype(np.float32)) for p in sets if p.size]
         n = sum(f.shape[0] for f in flat)
+        buf = None
         if n:
             fe = self.fe
             d_prev = torch.from_numpy(np.concatenate(flat, 0)).to(fe.device)
@@ -92,7 +100,12 @@ class SequenceTracker:
             _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, d_prev.data_ptr(), None,
                                           d_next.data_ptr(), d_st.data_ptr(), d_err.data_ptr(), n, self.criteria[0],
                                           self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
-            nxt, st, err = fe._unpack_outputs(buf, n)
+        return sets, buf, n
+
+    def _collect(self, launched):
+        sets, buf, n = launched
+        if n:
+            nxt, st, err = self.fe._unpack_outputs(buf, n)
         out, o = [], 0
         for p in sets:
             if p.size == 0:
@@ -102,6 +115,24 @@ class SequenceTracker:
             out.append((nxt[o:o + k].T, st[o:o + k], err[o:o + k]))
             o += k
         return out
+
+    def track_and_detect(self, img_current, point_sets, maxCorners, qualityLevel, minDistance, mask=None,
+                         useHarrisDetector=False, k=0.04):
+        """One frame of the reference's front end with its two independent halves overlapped on the GPU: the tracking of
+        every point set into img_current (continuous.py:86-87, 389-390) runs on the tracker's stream while
+        goodFeaturesToTrack(img_current) (continuous.py:380-385) runs on a second context and stream.  Neither reads what
+        the other writes, so the results are those of track() followed by detect(), bit for bit; the frame costs about
+        the longer of the two instead of their sum.  Returns (list of triples, corners)."""
+        if self._det_fe is None:
+            self._det_stream = torch.cuda.Stream(device=self.fe.device)
+            self._det_fe = FrontEnd(self.fe.device.index, stream=self._det_stream)
+        launched = self._launch(img_current, point_sets)       # upload, pyramid, LK launch: asynchronous
+        img = self._img[self.frame_index & 1]
+        self._det_stream.wait_event(self._uploaded)            # only the upload: not the pyramid or the tracker launch
+        with torch.cuda.stream(self._det_stream):
+            corners = self._det_fe.goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance, mask=mask,
+                                                       useHarrisDetector=useHarrisDetector, k=k)
+        return self._collect(launched), corners
 
     def detect(self, maxCorners, qualityLevel, minDistance, mask=None, useHarrisDetector=False, k=0.04):
         """cv2.goodFeaturesToTrack on the current frame (continuous.py:380-385) without another upload."""
@@ -114,6 +145,9 @@ class SequenceTracker:
         if self.pyr is not None:
             self.pyr.free()
             self.pyr = None
+        if self._det_fe is not None:
+            self._det_fe.close()
+            self._det_fe = None
         if self._own_fe and self.fe is not None:
             self.fe.close()
         self.fe = None
