@@ -51,7 +51,8 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->ws = nullptr; c->ws_bytes = 0;
-    c->h_pinned = nullptr; c->h_pinned_ints = 0;
+    c->h_pinned = nullptr; c->d_pinned = nullptr; c->h_pinned_ints = 0;
+    c->gftt_clean_batch = 0; c->gftt_clean_ws = nullptr;
     c->lk_counters = nullptr;
     *out = c;
     return VOFE_OK;

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, 
 // exclusive scan of the bucket histogram in (bucket, copy) order: one 1024-thread block per image,
 // N_BUCKET/1024 consecutive buckets per thread -> scatter cursors, the candidate count, and the
 // prefix lengths seg_end[k] = first bucket boundary >= min(n, base << k) (base = 0: everything).
-__global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
+__global__ __launch_bounds__(1024) void bucket_scan(unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                     GfttHdr* __restrict__ hdr, unsigned base) {
     __shared__ unsigned s_w[16];
     __shared__ unsigned s_n;
@@ -350,7 +350,13 @@ __global__ __launch_bounds__(1024) void bucket_scan(const unsigned* __restrict__
             const uint4 v = reinterpret_cast<const uint4*>(hs + (size_t)c * N_BUCKET)[t * (BPT / 4) + i];
             cnt[4 * i][c] = v.x; cnt[4 * i + 1][c] = v.y; cnt[4 * i + 2][c] = v.z; cnt[4 * i + 3][c] = v.w;
             mine += v.x + v.y + v.z + v.w;
+            // the histogram has been consumed: leave it zero for the next call (no memset command per call)
+            reinterpret_cast<uint4*>(hist + ((size_t)blockIdx.x * N_COPY + c) * N_BUCKET)[t * (BPT / 4) + i] = make_uint4(0u, 0u, 0u, 0u);
         }
+    // likewise the header fields the next call expects to be zero; max_key was last read by nms_map, the accepted
+    // count and the round flags are first touched by the selection that follows this kernel
+    if (t < SELECT_ROUNDS) hdr[blockIdx.x].undecided[t] = 0u;
+    if (t == SELECT_ROUNDS) { hdr[blockIdx.x].max_key = 0u; hdr[blockIdx.x].n_acc = 0u; }
     unsigned inc = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = (unsigned)__shfl_up((int)inc, o);
@@ -720,7 +726,13 @@ __global__ __launch_bounds__(256) void rank_count(const unsigned long long* __re
 }
 __global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __restrict__ keys, const GfttHdr* __restrict__ hdr,
                                                    size_t key_stride, const unsigned* __restrict__ rank, size_t rank_stride,
-                                                   int w, float* __restrict__ corners, int out_stride, int max_out) {
+                                                   int w, float* __restrict__ corners, int out_stride, int max_out,
+                                                   GfttHdr* __restrict__ host_hdr, float* __restrict__ host_corners) {
+    // host_hdr / host_corners: pinned host memory mapped into the device.  The last kernel of a call writes what the
+    // host needs there itself, so the call ends with a stream synchronisation and no device-to-host copy commands
+    // (each of those costs ~10 us of latency behind the kernels).
+    if (host_hdr && blockIdx.x == 0 && threadIdx.x < sizeof(GfttHdr) / 4)
+        reinterpret_cast<unsigned*>(host_hdr + blockIdx.y)[threadIdx.x] = reinterpret_cast<const unsigned*>(hdr + blockIdx.y)[threadIdx.x];
     const unsigned n = hdr[blockIdx.y].n_acc;
     if (n > RANK_MAX) return;
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -728,7 +740,9 @@ __global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __r
         if (rk >= (unsigned)max_out) continue;
         const unsigned p = (unsigned)(keys[(size_t)blockIdx.y * key_stride + i] & 0xffffffffull);
         const unsigned y = p / (unsigned)w;
-        reinterpret_cast<float2*>(corners)[(size_t)blockIdx.y * out_stride + rk] = make_float2((float)(p - y * w), (float)y);
+        const float2 c = make_float2((float)(p - y * w), (float)y);
+        reinterpret_cast<float2*>(corners)[(size_t)blockIdx.y * out_stride + rk] = c;
+        if (host_corners) reinterpret_cast<float2*>(host_corners)[rk] = c;
     }
 }
 
@@ -740,6 +754,7 @@ static int env_int(const char* name, int dflt) {
 int ensure_ws(vofe_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return VOFE_OK;
     if (ctx->ws) { hipStreamSynchronize(ctx->stream); hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    ctx->gftt_clean_batch = 0;                     // a new allocation starts dirty
     hipError_t e = hipMalloc(&ctx->ws, bytes);
     if (e != hipSuccess) return vofe_hip_fail(e, "hipMalloc(gftt workspace)");
     ctx->ws_bytes = bytes;
@@ -747,10 +762,12 @@ int ensure_ws(vofe_ctx* ctx, size_t bytes) {
 }
 int ensure_pinned(vofe_ctx* ctx, size_t ints) {
     if (ctx->h_pinned_ints >= ints) return VOFE_OK;
-    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-    ctx->h_pinned = nullptr; ctx->h_pinned_ints = 0;
-    hipError_t e = hipHostMalloc((void**)&ctx->h_pinned, ints * sizeof(int), hipHostMallocDefault);
+    if (ctx->h_pinned) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->h_pinned); }
+    ctx->h_pinned = nullptr; ctx->d_pinned = nullptr; ctx->h_pinned_ints = 0;
+    hipError_t e = hipHostMalloc((void**)&ctx->h_pinned, ints * sizeof(int), hipHostMallocMapped);
     if (e != hipSuccess) return vofe_hip_fail(e, "hipHostMalloc");
+    e = hipHostGetDevicePointer((void**)&ctx->d_pinned, ctx->h_pinned, 0);
+    if (e != hipSuccess) return vofe_hip_fail(e, "hipHostGetDevicePointer");
     ctx->h_pinned_ints = ints;
     return VOFE_OK;
 }
@@ -843,7 +860,11 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         seg_base = (unsigned)std::min<unsigned long long>(b0, 1u << 24);
     }
 
-    VOFE_HIP(hipMemsetAsync(base, 0, hdr_bytes + hist_bytes, st));
+    // header + histogram start a call at zero: bucket_scan leaves them so, a memset is needed only for a fresh or
+    // re-laid-out workspace (the layout depends on the batch) or after a call that did not run to its end
+    if (ctx->gftt_clean_batch != batch || ctx->gftt_clean_ws != ctx->ws)
+        VOFE_HIP(hipMemsetAsync(base, 0, hdr_bytes + hist_bytes, st));
+    ctx->gftt_clean_batch = 0;
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
@@ -889,13 +910,13 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             ub = std::min<unsigned long long>(std::min<unsigned long long>(ub + ub / 4, px), RANK_MAX);
             const unsigned gi = (unsigned)((ub + 255) / 256), gj = (unsigned)((ub + RANK_J - 1) / RANK_J);
             hipLaunchKernelGGL(rank_count, dim3(gi, gj, batch), dim3(256), 0, st, keys, hdr, px, rank, px);
+            // the emit kernel delivers header and (single image) corner list straight into pinned host memory
             hipLaunchKernelGGL(emit_ranked, dim3(gi, batch), dim3(256), 0, st, keys, hdr, px, rank, px, w, d_corners_xy,
-                               capacity, max_out);
+                               capacity, max_out, reinterpret_cast<GfttHdr*>(ctx->d_pinned),
+                               stage_floats ? reinterpret_cast<float*>(ctx->d_pinned + hdr_ints) : nullptr);
+        } else {
+            VOFE_HIP(hipMemcpyAsync(hh, hdr, sizeof(GfttHdr) * batch, hipMemcpyDeviceToHost, st));
         }
-        if (stage_floats && use_rank)
-            VOFE_HIP(hipMemcpyAsync(reinterpret_cast<int*>(ctx->h_pinned) + hdr_ints, d_corners_xy, stage_floats * sizeof(float),
-                                    hipMemcpyDeviceToHost, st));
-        VOFE_HIP(hipMemcpyAsync(hh, hdr, sizeof(GfttHdr) * batch, hipMemcpyDeviceToHost, st));
         VOFE_HIP(hipStreamSynchronize(st));
         bool converged = true, enough = true;
         for (int b = 0; b < batch; ++b) {
@@ -919,6 +940,8 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         }
         if (pass > 4096) { vofe_set_error("vofe_gftt: selection did not converge"); return VOFE_E_HIP; }
     }
+    ctx->gftt_clean_batch = batch;                 // bucket_scan left max_key and the histograms of this layout at zero
+    ctx->gftt_clean_ws = ctx->ws;
     unsigned nmax = 0;
     for (int b = 0; b < batch; ++b) {
         const unsigned n = hh[b].n_acc;

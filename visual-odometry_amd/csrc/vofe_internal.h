@@ -26,8 +26,11 @@ struct vofe_ctx {
     // GFTT workspace (grown on demand)
     void* ws;
     size_t ws_bytes;
-    int* h_pinned;            // small pinned readback buffer
+    int* h_pinned;            // small pinned readback buffer (mapped: kernels write results into it directly)
+    int* d_pinned;            // the same buffer as the device addresses it
     size_t h_pinned_ints;
+    int gftt_clean_batch;     // batch count whose header/histogram layout the last detector call left zeroed (0: none)
+    void* gftt_clean_ws;      // ... in this workspace allocation
     unsigned long long* lk_counters;   // optional device counters (vofe_lk_set_counters)
 };
 

@@ -92,20 +92,19 @@ class SequenceTracker:
         sets = [np.asarray(p) for p in point_sets]
         flat = [np.ascontiguousarray(p.T.reshape(-1, 2).astype(np.float32)) for p in sets if p.size]
         n = sum(f.shape[0] for f in flat)
-        buf = None
+        io = None
         if n:
             fe = self.fe
-            d_prev = torch.from_numpy(np.concatenate(flat, 0)).to(fe.device)
-            buf, d_next, d_err, d_st = fe._packed_outputs(n)
-            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, d_prev.data_ptr(), None,
-                                          d_next.data_ptr(), d_st.data_ptr(), d_err.data_ptr(), n, self.criteria[0],
-                                          self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
-        return sets, buf, n
+            io = fe._points_io(np.concatenate(flat, 0))
+            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, io["prev"], None, io["next"],
+                                          io["status"], io["err"], n, self.criteria[0], self.criteria[1], self.criteria[2],
+                                          self.min_eig, self.fb_thresh))
+        return sets, io, n
 
     def _collect(self, launched):
-        sets, buf, n = launched
+        sets, io, n = launched
         if n:
-            nxt, st, err = self.fe._unpack_outputs(buf, n)
+            nxt, st, err = self.fe._points_done(io)
         out, o = [], 0
         for p in sets:
             if p.size == 0:
