@@ -9,6 +9,9 @@
  *
  * Ownership: the caller owns every image / point / status / err buffer (device memory, e.g.
  * torch.Tensor.data_ptr()); the library owns only the ctx workspace and vofe_pyr objects.
+ * "Device pointer" means any address the device can access: for the few-KB point / status / err
+ * arrays, pinned host memory mapped into the device (hipHostMalloc + hipHostGetDevicePointer) works
+ * and saves the copy commands -- the shipped Python mirror passes its point sets that way.
  * Threading: a ctx is bound to one device and one stream and is not thread-safe; use one ctx
  * per thread / GPU.  Launches are asynchronous on the ctx stream unless stated otherwise.
  *
@@ -85,7 +88,9 @@ int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
 
 /* Replaces ContinuousVO._track_keypoints (reference continuous.py:131-164) in one launch:
  * forward LK, backward LK from every forward output, status &= max|prev - back| < fb_thresh
- * (the backward status is ignored, as at continuous.py:150,158).  Both pyramids need derivatives. */
+ * (the backward status is ignored, as at continuous.py:150,158).  Both pyramids need derivatives.
+ * A keypoint the forward pass loses is not tracked backward: its status is 0 whatever the backward
+ * pass would find, and no backward result is returned. */
 int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
                   int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
