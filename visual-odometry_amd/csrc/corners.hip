@@ -491,7 +491,7 @@ __device__ __forceinline__ bool sel_eval(const unsigned* __restrict__ ck, uint16
     }
     bool any_rej = __any(rej), any_blk = __any(blk);
     for (int spin = 0; !any_rej && any_blk && spin < spins; ++spin) {
-        if (spin) __builtin_amdgcn_s_sleep(8);
+        if (spin) __builtin_amdgcn_s_sleep(2);
         rej = false; blk = false;
 #pragma unroll
         for (int i = 0; i < SEL_CH; ++i) {
@@ -848,9 +848,9 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
 
     const bool suppress = min_distance >= 1.0;
     static const int sel_blocks = std::max(env_int("VOFE_SEL_BLOCKS", 1024), 1);
-    static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 2), 1), SELECT_ROUNDS);
-    static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 4), 1);
-    static const int sel_spins = std::max(env_int("VOFE_SEL_SPINS", 4), 0);
+    static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 1), 1), SELECT_ROUNDS);
+    static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 2), 1);
+    static const int sel_spins = std::max(env_int("VOFE_SEL_SPINS", 64), 0);
     static const int sel_prefix = std::max(env_int("VOFE_SEL_PREFIX", 2), 1);
     // first rank prefix: without suppression the best maxCorners candidates are the answer; with it,
     // a few times maxCorners candidates usually hold maxCorners accepted ones (grown x2 otherwise)
