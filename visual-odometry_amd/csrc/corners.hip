@@ -17,6 +17,8 @@
 #include <cstring>
 #include <vector>
 
+#include <cstdio>
+
 #include "vofe_internal.h"
 
 namespace {
@@ -923,6 +925,9 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             if (suppress && hh[b].undecided[sel_launches - 1]) converged = false;
             if (hh[b].seg_end[seg] < hh[b].n_cand && (max_corners <= 0 || hh[b].n_acc < (unsigned)max_corners)) enough = false;
         }
+        if (getenv("VOFE_GFTT_DEBUG"))
+            fprintf(stderr, "gftt pass %d seg %d: n_cand %u seg_end %u n_acc %u undecided %u converged %d enough %d\n", pass, seg,
+                    hh[0].n_cand, hh[0].seg_end[seg], hh[0].n_acc, hh[0].undecided[sel_launches - 1], (int)converged, (int)enough);
         if (converged && enough) break;
         if (converged && seg < N_SEG - 1) {
             // every image's prefix is final: widen it to where the acceptance rate seen so far (which
