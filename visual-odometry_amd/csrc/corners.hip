@@ -33,8 +33,10 @@ constexpr int BUCKET_BITS = 14;                 // (bucket << 2 | state) must fi
 static_assert(BUCKET_BITS <= 14, "bucket index is stored in 14 bits");
 constexpr int N_BUCKET = 1 << BUCKET_BITS;      // score buckets of the coarse rank order (fine: few atomics collide)
 
+constexpr int MAX_SLOTS = 32;
 struct GfttHdr {
-    unsigned max_key;       // order-preserving key of the global score maximum (0 = none)
+    unsigned max_key[MAX_SLOTS];   // order-preserving key of the global score maximum (0 = none), spread over slots:
+                                   // same-address atomics serialise (~10 ns each), the readers take the max of all
     unsigned n_cand;
     unsigned n_acc;
     unsigned pad;
@@ -144,8 +146,8 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
         if ((tid & 63) == 0 && best) atomicMax(&sMax, best);
         __syncthreads();
         // same-address atomics serialise (~10 ns each): only blocks that can still raise the maximum issue one
-        if (tid == 0 && sMax > __hip_atomic_load(&hdr[blockIdx.z].max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&hdr[blockIdx.z].max_key, sMax);
+        unsigned* slot = &hdr[blockIdx.z].max_key[(blockIdx.x + 5 * blockIdx.y) & (MAX_SLOTS - 1)];
+        if (tid == 0 && sMax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, sMax);
     }
 }
 
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
     }
     if (hdr) {
         for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
-        if (lane == 0 && best > __hip_atomic_load(&hdr[blockIdx.z].max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&hdr[blockIdx.z].max_key, best);
+        unsigned* slot = &hdr[blockIdx.z].max_key[(blockIdx.x * 4 + wv + 7 * blockIdx.y) & (MAX_SLOTS - 1)];
+        if (lane == 0 && best) atomicMax(slot, best);           // no pre-check load: it would only add an L2 round trip
     }
 }
 
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, 
     const int y0 = blockIdx.y * (4 * NMS_ROWS) + wv;
     const size_t ib = (size_t)blockIdx.z * h * w;
     const float* sc = score + ib;
-    const unsigned mk = hdr[blockIdx.z].max_key;
+    unsigned mk = hdr[blockIdx.z].max_key[lane & (MAX_SLOTS - 1)];       // wave-wide maximum of the slots
+    for (int o = MAX_SLOTS / 2; o > 0; o >>= 1) mk = max(mk, (unsigned)__shfl_xor((int)mk, o));
     const float thr = gftt_threshold(mk, quality);
     const BucketMap bm = bucket_map(mk, thr);
     unsigned* hs = hist + ((size_t)blockIdx.z * N_COPY + tile_copy(blockIdx.x * 64, blockIdx.y * (4 * NMS_ROWS))) * N_BUCKET;
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(1024) void bucket_scan(unsigned* __restrict__ hist,
     // likewise the header fields the next call expects to be zero; max_key was last read by nms_map, the accepted
     // count and the round flags are first touched by the selection that follows this kernel
     if (t < SELECT_ROUNDS) hdr[blockIdx.x].undecided[t] = 0u;
-    if (t == SELECT_ROUNDS) { hdr[blockIdx.x].max_key = 0u; hdr[blockIdx.x].n_acc = 0u; }
+    if (t == SELECT_ROUNDS) hdr[blockIdx.x].n_acc = 0u;
+    if (t >= 64 && t < 64 + MAX_SLOTS) hdr[blockIdx.x].max_key[t - 64] = 0u;
     unsigned inc = mine;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = (unsigned)__shfl_up((int)inc, o);
@@ -796,9 +800,14 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
             if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
             hipLaunchKernelGGL(corner_score_strip<8>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
-        } else {
+        } else if (waves8 >= 512 || getenv("VOFE_SCORE_RS4")) {
             dim3 grid((w + 255) / 256, (h + 15) / 16, batch);
             hipLaunchKernelGGL(corner_score_strip<4>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
+                               d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+        } else {
+            // a single small frame: 2-row strips double the wave count again (the kernel is pure latency there)
+            dim3 grid((w + 255) / 256, (h + 7) / 8, batch);
+            hipLaunchKernelGGL(corner_score_strip<2>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
         }
     } else {
