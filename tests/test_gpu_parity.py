@@ -497,6 +497,38 @@ def test_sequence_tracker_overlapped_track_and_detect(fe):
     a.close(); b.close()
 
 
+def test_multi_sequence_tracker_equals_independent_trackers(fe):
+    """configs[3] at the user level: B sequences advanced by one pyramid build + one launch per frame index give what
+    B independent SequenceTrackers give (ragged point counts, one sequence without points, batched detection)."""
+    from visual_odometry_amd import SequenceTracker, MultiSequenceTracker
+    B, h, w = 5, 200, 320
+    seqs = [_seq(h, w, 700 + s, 4) for s in range(B)]
+    multi = MultiSequenceTracker(B, h, w, frontend=fe)
+    singles = [SequenceTracker(h, w, frontend=fe) for _ in range(B)]
+    multi.reset(np.stack([q[0] for q in seqs]))
+    for s, t in enumerate(singles):
+        t.reset(seqs[s][0])
+    det = multi.detect(150, 0.01, 8)
+    pts = []
+    for s in range(B):
+        ref = singles[s].detect(150, 0.01, 8)
+        assert (det[s] is None) == (ref is None) and (ref is None or np.array_equal(det[s], ref))
+        pts.append(ref.reshape(-1, 2).T[:, : 150 - 37 * s] if s != 3 else np.empty((2, 0)))
+    for f in range(1, 4):
+        got = multi.track(np.stack([q[f] for q in seqs]), pts)
+        nxt = []
+        for s in range(B):
+            (rt, rs, re), = singles[s].track(seqs[s][f], pts[s])
+            gt, gs, ge = got[s]
+            assert gt.shape == rt.shape and np.array_equal(gt, rt) and np.array_equal(gs, rs) and np.array_equal(ge, re), (f, s)
+            nxt.append(rt[:, rs == 1] if rt.size else rt)
+        pts = nxt
+    assert sum(p.shape[1] for p in pts) > 200
+    multi.close()
+    for t in singles:
+        t.close()
+
+
 # ------------------------------------------------------------------ BASELINE.json full-size configurations
 @pytest.mark.parametrize("cfg,md", [("malaga", 10), ("stress", 10)])
 def test_full_size_config_front_end_frame(fe, cfg, md):

@@ -18,7 +18,7 @@ def __getattr__(name):
                 "default_frontend"):
         from . import frontend
         return getattr(frontend, name)
-    if name == "SequenceTracker":
-        from .sequence import SequenceTracker
-        return SequenceTracker
+    if name in ("SequenceTracker", "MultiSequenceTracker"):
+        from . import sequence
+        return getattr(sequence, name)
     raise AttributeError(name)

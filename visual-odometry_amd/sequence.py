@@ -150,3 +150,91 @@ class SequenceTracker:
         if self._own_fe and self.fe is not None:
             self.fe.close()
         self.fe = None
+
+
+class MultiSequenceTracker:
+    """B independent sequences of one geometry on one GPU (BASELINE configs[3]; SURVEY 8e: sequences are the only
+    unit the path shards over).  Per frame index: ONE pyramid build of the B new frames and ONE tracker launch over the
+    points of all sequences (a per-point image index selects the sequence), instead of B builds and B launches; the
+    detector runs batched too.  Results per sequence are those of B SequenceTrackers, bit for bit."""
+
+    def __init__(self, n_sequences, height, width, winSize=(21, 21), maxLevel=3, criteria=_DEFAULT_CRITERIA,
+                 minEigThreshold=1e-3, fb_thresh=1.0, frontend=None, device=0):
+        self.fe = frontend if frontend is not None else FrontEnd(device)
+        self._own_fe = frontend is None
+        self.B, self.h, self.w = int(n_sequences), int(height), int(width)
+        self.criteria = (int(criteria[0]), int(criteria[1]), float(criteria[2]))
+        self.min_eig = float(minEigThreshold)
+        self.fb_thresh = float(fb_thresh)
+        self.pyr = Pyramid(self.fe, 2 * self.B, self.h, self.w, winSize, maxLevel, True)   # two rings of B slots
+        self.frame_index = -1
+        self._img = [None, None]
+
+    def _push(self, frames):
+        if isinstance(frames, torch.Tensor):
+            d = frames.to(self.fe.device)
+        else:
+            a = np.ascontiguousarray(np.asarray(frames))
+            if a.dtype != np.uint8:
+                raise error(-1, "frames must be 8-bit")
+            d = torch.from_numpy(a).to(self.fe.device)
+        if tuple(d.shape) != (self.B, self.h, self.w) or d.dtype != torch.uint8:
+            raise error(-1, "need uint8 frames of shape (%d, %d, %d)" % (self.B, self.h, self.w))
+        self.frame_index += 1
+        ring = self.frame_index & 1
+        self.pyr.build(d, ring * self.B)
+        self._img[ring] = d
+        return ring
+
+    def reset(self, frames):
+        """First frame of every sequence: (B,H,W) uint8 (numpy or CUDA tensor)."""
+        self.frame_index = -1
+        self._push(frames)
+
+    def track(self, frames, point_sets):
+        """frames: the next frame of every sequence, (B,H,W); point_sets: B arrays (2,N_b) (N_b may be 0).
+        Returns B (tracked (2,N_b) f32, status (N_b,) u8, err (N_b,) f32) triples."""
+        if self.frame_index < 0:
+            raise error(-1, "MultiSequenceTracker.track before reset()")
+        if len(point_sets) != self.B:
+            raise error(-1, "need one point set per sequence")
+        prev_ring = self.frame_index & 1
+        next_ring = self._push(frames)
+        sets = [np.asarray(p) for p in point_sets]
+        flat = [np.ascontiguousarray(p.T.reshape(-1, 2).astype(np.float32)) if p.size else np.empty((0, 2), np.float32)
+                for p in sets]
+        counts = [f.shape[0] for f in flat]
+        n = sum(counts)
+        if n:
+            fe = self.fe
+            io = fe._points_io(np.concatenate(flat, 0))
+            idx = torch.from_numpy(np.repeat(np.arange(self.B, dtype=np.int32), counts)).to(fe.device)
+            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_ring * self.B, self.pyr._h, next_ring * self.B, io["prev"],
+                                          idx.data_ptr(), io["next"], io["status"], io["err"], n, self.criteria[0],
+                                          self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
+            nxt, st, err = fe._points_done(io)
+        out, o = [], 0
+        for k in counts:
+            if k == 0:
+                out.append((np.empty((2, 0)), np.empty((0,), dtype=np.uint8), np.empty((0,), dtype=np.float32)))
+                continue
+            out.append((nxt[o:o + k].T, st[o:o + k], err[o:o + k]))
+            o += k
+        return out
+
+    def detect(self, maxCorners, qualityLevel, minDistance, useHarrisDetector=False, k=0.04):
+        """cv2.goodFeaturesToTrack on the current frame of every sequence in one batched call: B arrays (N_b,1,2) / None."""
+        if self.frame_index < 0:
+            raise error(-1, "MultiSequenceTracker.detect before reset()")
+        out, cnt = self.fe.goodFeaturesToTrack_batch(self._img[self.frame_index & 1], maxCorners, qualityLevel, minDistance,
+                                                     useHarrisDetector=useHarrisDetector, k=k)
+        host = out.cpu().numpy()
+        return [host[b, :c].reshape(-1, 1, 2).copy() if c else None for b, c in enumerate(cnt)]
+
+    def close(self):
+        if self.pyr is not None:
+            self.pyr.free()
+            self.pyr = None
+        if self._own_fe and self.fe is not None:
+            self.fe.close()
+        self.fe = None
