@@ -858,6 +858,8 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     uint16_t* state = reinterpret_cast<uint16_t*>(maps + ((batch * px * 20 + 15) & ~(size_t)15));   // 16-byte aligned
 
     const bool suppress = min_distance >= 1.0;
+    // schedule of the selection (measured, profiles/r01_host_paths.txt; any values give the same corners, see
+    // tools/knob_matrix.sh): one launch of 4096 waves, two sweeps, a blocked candidate polls its blockers up to 64 times
     static const int sel_blocks = std::max(env_int("VOFE_SEL_BLOCKS", 1024), 1);
     static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 1), 1), SELECT_ROUNDS);
     static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 2), 1);

@@ -413,7 +413,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 }
 
 #undef LK_ROW
-// Register budget decides the occupancy (R = 7: 109 VGPRs -> 4 waves per SIMD).  Capping the allocation
+// Register budget decides the occupancy (21x21: 93 VGPRs -> 5 waves per SIMD).  Capping the allocation
 // further (amdgpu_waves_per_eu) was measured: the spills cost more than the occupancy gives.
 template <int R, int WC>
 __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
