@@ -228,7 +228,7 @@ def main():
     if rank == 0:
         alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_launch[1]), float(cnt_launch[2]))
         achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
-        kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if B * n >= 12288 else "lk_track_kernel<7, 21>"
+        kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if B * n >= 4000 else "lk_track_kernel<7, 21>"
         kernel = "%s: fwd + bwd + FB check of %d pairs x %d points in one launch" % (kname, B, n)
         out = {
             "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",

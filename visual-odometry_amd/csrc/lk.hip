@@ -213,7 +213,7 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
     }
 }
 
-constexpr int LK_X2_MIN_POINTS = 12288;    // below this a launch does not fill the GPU and latency matters more
+constexpr int LK_X2_MIN_POINTS = 4000;     // measured (scratch/lk_threshold.py, lk_bench.py): one per wavefront 5 % ahead at 3000 points, two per wavefront 8 % ahead at 4000
 constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
 
 // WC != 0: compile-time square window WC x WC with R * groups == WC (every active lane owns exactly R rows;
