@@ -5,7 +5,7 @@ One "LK frame"  = a synthetic KITTI-shaped pair: Gaussian pyramids
 of BOTH 1241x376 frames, forward LK of 2000 keypoints (21x21 window, 4 levels, criteria (30, 0.01),
 minEigThreshold 1e-3), backward LK from every forward result and the forward-backward check --
 exactly what ContinuousVO._track_keypoints asks of cv2 per call (reference continuous.py:131-164).
-One step = --batch independent LK frames (default 16) in one pyramid launch set + one LK launch.  Inputs (8 frames, point sets) are resident in HBM before the
+One step = --batch independent LK frames (default 64) in one pyramid launch set + one LK launch.  Inputs (8 frames, point sets) are resident in HBM before the
 timed region; every step goes through the C ABI (libvofe.so).  N > 1: each rank tracks its own
 independent sequence (seed 100 + rank) -- replicas only, no collective on the data path.
 
@@ -39,7 +39,8 @@ N_FRAMES = 8
 # (pairs per launch, points per pair).  The kernel's loads are narrow (2- and 8-byte gathers), a pattern for
 # which the guide gives no gfx950 FETCH_SIZE correction, so the raw value is reported; it is well below the
 # algorithmic bytes because the patches are served from L2 / MALL.
-LK7_PMC_TRAFFIC_BYTES = {(16, 2000): int((433516.4 + 1810.0) * 1024), (1, 2000): int((18081.0 + 142.9) * 1024)}
+LK7_PMC_TRAFFIC_BYTES = {(64, 2000): int((1747015.3 + 7919.3) * 1024), (16, 2000): int((433516.4 + 1810.0) * 1024),
+                         (1, 2000): int((18078.0 + 141.4) * 1024)}
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
@@ -55,7 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=2000)
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=64,
                     help="independent frame pairs per step: one pyramid launch set + one LK launch for all of them")
     ap.add_argument("--streams", type=int, default=2,
                     help="steps in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial steps")
