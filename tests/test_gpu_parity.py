@@ -305,11 +305,11 @@ def test_corner_score_bit_exact(fe, h, w, seed, harris):
 
 @pytest.mark.parametrize("path", ["strip", "tile"])
 def test_corner_score_kernel_paths_and_edges(fe, monkeypatch, path):
-    """Register-strip kernel (w >= 8, h >= 2) and LDS-tile kernel on widths/heights around every
+    """Register-strip kernel (w >= 8, h >= 4) and LDS-tile kernel on widths/heights around every
     internal boundary: 4-column threads, 256-column waves, 4/8-row strips, last-column position."""
     monkeypatch.setenv("VOFE_CORNER_SCORE", path)
     rng = np.random.default_rng(3)
-    for (h, w) in ((2, 8), (3, 9), (5, 10), (7, 11), (9, 12), (17, 255), (16, 256), (33, 257), (31, 258), (4, 259),
+    for (h, w) in ((2, 8), (3, 9), (4, 8), (4, 13), (5, 10), (6, 300), (7, 11), (9, 12), (17, 255), (16, 256), (33, 257), (31, 258), (4, 259),
                    (40, 515), (130, 64), (129, 1030)):
         a = rng.integers(0, 256, (h, w), dtype=np.uint8)
         for harris in (False, True):
@@ -317,9 +317,11 @@ def test_corner_score_kernel_paths_and_edges(fe, monkeypatch, path):
     for (h, w) in ((1100, 1300), (2170, 3000)):            # enough waves for the 8-row / 16-row strips
         big = _seq(h, w, 5, 1)[0]
         assert np.array_equal(fe.corner_score(big, False, 0.04), oracle.corner_score(big, False, 0.04, nthreads=8))
-    mask = np.zeros((129, 1030), np.uint8); mask[10:100, 500:1029] = 1
     a = _seq(129, 1030, 6, 1)[0]
-    assert np.array_equal(fe.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask), oracle.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask))
+    for (r0, r1, c0, c1) in ((10, 100, 500, 1029), (0, 129, 1020, 1030), (0, 40, 0, 300)):
+        mask = np.zeros((129, 1030), np.uint8); mask[r0:r1, c0:c1] = 1
+        assert np.array_equal(fe.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask),
+                              oracle.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask))
 
 
 @pytest.mark.parametrize("h,w,seed,maxc,q,md", [(376, 1241, 0, 1000, 0.01, 10), (376, 1241, 0, 2000, 0.01, 7),

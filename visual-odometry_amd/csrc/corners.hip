@@ -152,14 +152,34 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// score map, register-strip version (frames with w >= 8, h >= 2): one thread owns 4 adjacent columns
+// score map, register-strip version (frames with w >= 8, h >= 4): one thread owns 4 adjacent columns
 // and walks RS output rows; no LDS.  Per image row it loads the 8 bytes covering columns x-2..x+5 with
 // one unaligned load, keeps a 3-row ring of the horizontal Sobel terms, a 3-row ring of the f64
-// horizontal box sums of the three products, and emits one row of 4 scores per step.  Borders follow
-// the oracle exactly: REFLECT_101 on the image for the Sobel taps, REFLECT_101 on the product maps
-// for the box sums (column -1 := column 1, column w := column w-2, same for rows).  All float/double
+// horizontal box sums of the three products, and emits one row of 4 scores per step.  All float/double
 // operations are the ones of corner_score_f32 above, in the same order.
+//   Borders (REFLECT_101 on the image for the Sobel taps, REFLECT_101 on the product maps for the box
+// sums) cost no per-pixel select: pixels are fetched through the reflection, so the product row "-1"
+// is computed from image rows 2, 1, 0 - its dx equals row 1's (f32 addition commutes) and its dy is
+// row 1's negated (exactly): it IS product row 1 with dx*dy negated; likewise row h against row h-2
+// and, with dx and dy trading places, columns -1 and w.  Rows: the image row index is reflected and
+// the xy row sums of a reflected row change sign (a wave-uniform branch taken on at most two steps per
+// frame).  Columns: the 8 loaded bytes go through two v_perm_b32 whose per-thread selectors do the
+// alignment shift and the reflection at once, and five per-thread sign masks flip dx*dy of a
+// reflected product column (all zero except in the frame's first and last thread of a row).
 typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+
+// Correctly rounded sqrtf for an argument that is +0 or >= 2^-96: the compiler's own expansion (v_sqrt_f32, then the
+// neighbours one ulp below and above tested by the sign of their fused residuals) minus its rescaling of tiny
+// arguments and its zero/infinity select (a zero argument passes through the tests unchanged: both residuals compare
+// false).  The caller checks the range, wave-uniformly, and uses sqrtf otherwise.
+__device__ __forceinline__ float sqrt_rn_normal(float s) {
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
+    const float em = __builtin_fmaf(-rm, r, s), ep = __builtin_fmaf(-rp, r, s);
+    float q = (0.f >= em) ? rm : r;
+    q = (0.f < ep) ? rp : q;
+    return q;
+}
 
 template <int RS>
 __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restrict__ img, int h, int w, int pitch,
@@ -172,11 +192,23 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
     if (y0 >= h) return;                                  // whole wave (no block barrier below)
     const uint8_t* im = img + (size_t)blockIdx.z * img_stride;
     const bool live = x < w;
-    const int xa = min(max(x - 2, 0), w - 8);
-    const int sh = live ? (x - 2 - xa) * 8 : 0;           // -16, 0, 8 .. 40 bits
-    const int jw = w - 1 - x;                             // local index of the last image column (0..3: right border thread)
-    const bool lb = (x == 0);
+    const int xa = min(max(x - 2, 0), w - 8);             // first loaded column
     const float s1 = (float)(1.0 / 3060.0), s2 = (float)(2.0 / 3060.0);
+
+    // f[i] (i = 0..7) is image column x-2+i through REFLECT_101, as a byte index into the 8 loaded bytes
+    unsigned sel_lo = 0, sel_hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = x - 2 + i;
+        c = c < 0 ? -c : c;
+        c = c >= w ? 2 * w - 2 - c : c;
+        const unsigned b = (unsigned)min(max(c - xa, 0), 7);      // clamped: bytes that only feed unused columns
+        if (i < 4) sel_lo |= b << (8 * i); else sel_hi |= b << (8 * (i - 4));
+    }
+    // product column c (c = 0..5) is image column x-1+c; a reflected one (-1 or w) carries -dx*dy
+    unsigned sgn[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sgn[c] = (x - 1 + c < 0 || x - 1 + c == w) ? 0x80000000u : 0u;
 
     unsigned long long bits[RS + 4];
 #pragma unroll
@@ -191,20 +223,16 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
 
     float hd[3][6], hs[3][6];
     double rsum[3][3][4];
-    unsigned best = 0;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int t = 0; t < RS + 4; ++t) {
         // ---- horizontal Sobel terms of image row y0-2+t
         {
-            const unsigned long long v = sh < 0 ? bits[t] << 16 : bits[t] >> sh;
-            const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+            const unsigned rl = (unsigned)bits[t], rh = (unsigned)(bits[t] >> 32);
+            const unsigned lo = __builtin_amdgcn_perm(rh, rl, sel_lo), hi = __builtin_amdgcn_perm(rh, rl, sel_hi);
             float f[8];
             f[0] = (float)(lo & 0xffu); f[1] = (float)((lo >> 8) & 0xffu); f[2] = (float)((lo >> 16) & 0xffu); f[3] = (float)(lo >> 24);
             f[4] = (float)(hi & 0xffu); f[5] = (float)((hi >> 8) & 0xffu); f[6] = (float)((hi >> 16) & 0xffu); f[7] = (float)(hi >> 24);
-            if (lb) f[1] = f[3];                          // I[-1] = I[1]
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj)                // jw == 4: the last column is this thread's right halo
-                if (jw == jj) f[jj + 3] = f[jj + 1];      // I[w] = I[w-2]
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 hd[t % 3][c] = f[c + 2] - f[c];
@@ -220,12 +248,9 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
             for (int c = 0; c < 6; ++c) {
                 const float dx = s2 * hd[mid][c] + s1 * (hd[top][c] + hd[bot][c]);
                 const float dy = hs[bot][c] - hs[top][c];
-                pxx[c] = dx * dx; pxy[c] = dx * dy; pyy[c] = dy * dy;
+                pxx[c] = dx * dx; pyy[c] = dy * dy;
+                pxy[c] = __uint_as_float(__float_as_uint(dx * dy) ^ sgn[c]);
             }
-            if (lb) { pxx[0] = pxx[2]; pxy[0] = pxy[2]; pyy[0] = pyy[2]; }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jw == jj) { pxx[jj + 2] = pxx[jj]; pxy[jj + 2] = pxy[jj]; pyy[jj + 2] = pyy[jj]; }
             const int slot = t % 3;
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
@@ -233,34 +258,45 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
                 rsum[slot][1][o] = ((double)pxy[o] + (double)pxy[o + 1]) + (double)pxy[o + 2];
                 rsum[slot][2][o] = ((double)pyy[o] + (double)pyy[o + 1]) + (double)pyy[o + 2];
             }
+            const int v = y0 - 3 + t;
+            if (v < 0 || v >= h) {                        // uniform: a reflected row
+#pragma unroll
+                for (int o = 0; o < 4; ++o) rsum[slot][1][o] = -rsum[slot][1][o];
+            }
         }
         if (t < 4) continue;
         // ---- output row y = y0-4+t from the row sums of rows y-1, y, y+1 (slots t-2, t-1, t)
         const int y = y0 - 4 + t;
         if (y >= h) break;                                // uniform
-        const int sa = (y == 0) ? t % 3 : (t - 2) % 3;    // row -1 := row 1
-        const int sb = (t - 1) % 3;
-        const int sc = (y == h - 1) ? (t - 2) % 3 : t % 3; // row h := row h-2
         float out[4];
+        float c[4][3];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            // slot selection is uniform; written as selects so that the ring stays in registers
-            float c[3];
+        for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const double A = (y == 0) ? rsum[t % 3][ch][o] : rsum[(t - 2) % 3][ch][o];
-                const double B = rsum[(t - 1) % 3][ch][o];
-                const double C = (y == h - 1) ? rsum[(t - 2) % 3][ch][o] : rsum[t % 3][ch][o];
-                c[ch] = (float)((A + B) + C);
+            for (int ch = 0; ch < 3; ++ch)
+                c[o][ch] = (float)((rsum[(t - 2) % 3][ch][o] + rsum[(t - 1) % 3][ch][o]) + rsum[t % 3][ch][o]);
+        if (!harris) {
+            float tr[4], ss[4];
+            unsigned lowest = 0xffffffffu;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float a = c[o][0] * 0.5f, b = c[o][1], cc = c[o][2] * 0.5f;
+                tr[o] = a + cc;
+                ss[o] = (a - cc) * (a - cc) + b * b;                         // >= +0
+                lowest = min(lowest, __float_as_uint(ss[o]) - 1u);          // +0 wraps to the top
             }
-            if (!harris) {
-                const float a = c[0] * 0.5f, b = c[1], cc = c[2] * 0.5f;
-                out[o] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+            if (!__any(lowest < 0x0f800000u - 1u)) {                        // nothing in (0, 2^-96): the usual case
+#pragma unroll
+                for (int o = 0; o < 4; ++o) out[o] = tr[o] - sqrt_rn_normal(ss[o]);
             } else {
-                out[o] = (c[0] * c[2] - c[1] * c[1]) - kf * ((c[0] + c[2]) * (c[0] + c[2]));
+#pragma unroll
+                for (int o = 0; o < 4; ++o) out[o] = tr[o] - sqrtf(ss[o]);
             }
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                out[o] = (c[o][0] * c[o][2] - c[o][1] * c[o][1]) - kf * ((c[o][0] + c[o][2]) * (c[o][0] + c[o][2]));
         }
-        (void)sa; (void)sb; (void)sc;
         if (live) {
             float* dst = score + ((size_t)blockIdx.z * h + y) * w + x;
             if (x + 3 < w) {
@@ -271,17 +307,28 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
 #pragma unroll
                 for (int o = 0; o < 4; ++o) if (x + o < w) dst[o] = out[o];
             }
-            if (hdr) {
+        }
+        if (hdr) {                                        // uniform
+            if (mask) {                                   // uniform
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
-                    if (x + o < w && (!mask || mask[(size_t)y * w + x + o])) best = max(best, float_key(out[o]));
+                    if (x + o < w && mask[(size_t)y * w + x + o]) best[o] = fmaxf(best[o], out[o]);
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) best[o] = fmaxf(best[o], out[o]);   // columns >= w are dropped below
             }
         }
     }
     if (hdr) {
-        for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+        // scores are never -inf or NaN, so the float maximum orders as the keys do (the sign of a zero maximum is
+        // immaterial: the threshold it yields compares the same)
+        float bf = -INFINITY;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) if (x + o < w) bf = fmaxf(bf, best[o]);
+        unsigned bk = bf == -INFINITY ? 0u : float_key(bf);
+        for (int o = 32; o > 0; o >>= 1) bk = max(bk, (unsigned)__shfl_xor((int)bk, o));
         unsigned* slot = &hdr[blockIdx.z].max_key[(blockIdx.x * 4 + wv + 7 * blockIdx.y) & (MAX_SLOTS - 1)];
-        if (lane == 0 && best) atomicMax(slot, best);           // no pre-check load: it would only add an L2 round trip
+        if (lane == 0 && bk) atomicMax(slot, bk);               // no pre-check load: it would only add an L2 round trip
     }
 }
 
@@ -785,9 +832,11 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
                              unsigned* d_hdr, const uint8_t* d_mask) {
     if (batch > 65535) { vofe_set_error("corner_score: batch too large"); return VOFE_E_UNSUPPORTED; }
     const char* force = getenv("VOFE_CORNER_SCORE");             // "tile" forces the LDS-tile kernel (tests)
-    if (w >= 8 && h >= 2 && !(force && force[0] == 't')) {
+    if (w >= 8 && h >= 4 && !(force && force[0] == 't')) {
         // strips of 8 rows; 4 rows while that leaves SIMDs without a wave (small frames are latency bound)
-        const long long waves8 = (long long)((w + 255) / 256) * ((h + 7) / 8) * batch;
+        long long waves8 = (long long)((w + 255) / 256) * ((h + 7) / 8) * batch;
+        if (const char* rs = getenv("VOFE_SCORE_RS"))            // 2, 4, 8 or 16 rows per strip (tests, tuning)
+            waves8 = atoi(rs) >= 16 ? 3072 : atoi(rs) >= 8 ? 1024 : atoi(rs) >= 4 ? 512 : 0;
         if (waves8 >= 3072) {
             // more 8-row waves than the chip holds at once (3 per SIMD at this register count): 16-row strips
             // halve the wave count and trim the 4 halo rows per strip
@@ -800,7 +849,7 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
             if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
             hipLaunchKernelGGL(corner_score_strip<8>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
-        } else if (waves8 >= 512 || getenv("VOFE_SCORE_RS4")) {
+        } else if (waves8 >= 512) {
             dim3 grid((w + 255) / 256, (h + 15) / 16, batch);
             hipLaunchKernelGGL(corner_score_strip<4>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
