@@ -870,3 +870,31 @@ def test_randomised_gftt_sweep(fe):
         assert (got is None) == (ref is None), (case, h, w, q, md, maxc)
         if ref is not None:
             assert np.array_equal(got, ref), (case, h, w, q, md, maxc, harris)
+
+
+def test_randomised_score_sweep(fe, monkeypatch):
+    """Score maps of random frames, bit for bit: sizes around the strip kernel's internal boundaries (4-column
+    threads, 256-column waves, strip heights), every strip height forced in turn, smooth / noisy / posterised /
+    saturated content, Shi-Tomasi and Harris."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 99)))
+    for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40))):
+        h = int(rng.choice([4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, int(rng.integers(4, 200))]))
+        w = int(rng.choice([8, 9, 10, 11, 12, 13, 255, 256, 257, 258, 259, 260, 261, 511, 513, int(rng.integers(8, 700))]))
+        kind = case % 4
+        if kind == 0:
+            a = _seq(h, w, 900 + case, 1)[0]
+        elif kind == 1:
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 2:
+            a = (_seq(h, w, 900 + case, 1)[0] // 64 * 64).astype(np.uint8)
+        else:
+            a = np.where(rng.random((h, w)) > 0.5, 255, 0).astype(np.uint8)
+            a[: h // 2] = 255                                          # large flat part: zero scores, zero sqrt arguments
+        rs = ("2", "4", "8", "16", None)[case % 5]
+        if rs is None:
+            monkeypatch.delenv("VOFE_SCORE_RS", raising=False)
+        else:
+            monkeypatch.setenv("VOFE_SCORE_RS", rs)
+        harris = bool(case % 3 == 0)
+        assert np.array_equal(fe.corner_score(a, harris, 0.04), oracle.corner_score(a, harris, 0.04)), (case, h, w, kind, rs, harris)

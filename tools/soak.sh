@@ -7,6 +7,6 @@ for seed in "${@:-11 12 13}"; do
   for s in $seed; do
     echo "== seed $s, $cases cases per sweep"
     VOFE_SWEEP_CASES=$cases VOFE_SWEEP_SEED=$s timeout -k 10 900 python3 -u -m pytest tests/test_gpu_parity.py -x -q \
-        --timeout 800 --timeout-method thread -k "randomised" 2>&1 | tail -3 || exit 1
+        --timeout 800 --timeout-method thread -k "${SOAK_TESTS:-randomised}" 2>&1 | tail -3 || exit 1
   done
 done
