@@ -13,7 +13,9 @@
  * arrays, pinned host memory mapped into the device (hipHostMalloc + hipHostGetDevicePointer) works
  * and saves the copy commands -- the shipped Python mirror passes its point sets that way.
  * Threading: a ctx is bound to one device and one stream and is not thread-safe; use one ctx
- * per thread / GPU.  Launches are asynchronous on the ctx stream unless stated otherwise.
+ * per thread / GPU.  Launches are asynchronous on the ctx stream unless stated otherwise.  Every
+ * entry point that touches the device makes the ctx's device current for the calling thread
+ * (hipSetDevice) and leaves it current.
  *
  * There is no CPU fallback in this library: without a usable gfx950 device vofe_create fails.
  */

@@ -23,6 +23,16 @@ int vofe_hip_fail(hipError_t e, const char* what) {
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 
+// Every launching entry point makes the ctx's device current for the calling thread (a thread-local read when it
+// already is), so a process that drives several GPUs from one thread cannot launch on the wrong one.
+static int bind_device(const vofe_ctx* ctx) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return VOFE_OK;
+    VOFE_HIP(hipSetDevice(ctx->device));
+    return VOFE_OK;
+}
+#define VOFE_BIND(ctx) do { int rc_ = bind_device(ctx); if (rc_) return rc_; } while (0)
+
 extern "C" {
 
 const char* vofe_last_error(void) { return g_err; }
@@ -47,7 +57,7 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
         return VOFE_E_UNSUPPORTED;
     }
     vofe_ctx* c = new (std::nothrow) vofe_ctx();
-    if (!c) return VOFE_E_NOMEM;
+    if (!c) { vofe_set_error("vofe_create: out of host memory"); return VOFE_E_NOMEM; }
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->ws = nullptr; c->ws_bytes = 0;
@@ -70,6 +80,7 @@ int vofe_destroy(vofe_ctx* ctx) {
 
 int vofe_synchronize(vofe_ctx* ctx) {
     if (!ctx) { vofe_set_error("vofe_synchronize: ctx is NULL"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
     VOFE_HIP(hipStreamSynchronize(ctx->stream));
     return VOFE_OK;
 }
@@ -85,8 +96,9 @@ int vofe_pyramid_create(vofe_ctx* ctx, int slots, int height, int width, int win
         return VOFE_E_ARG;
     }
     if (height + 2 * win_h > 65535) { vofe_set_error("vofe_pyramid_create: image too tall (%d rows)", height); return VOFE_E_UNSUPPORTED; }
+    VOFE_BIND(ctx);
     vofe_pyr* p = new (std::nothrow) vofe_pyr();
-    if (!p) return VOFE_E_NOMEM;
+    if (!p) { vofe_set_error("vofe_pyramid_create: out of host memory"); return VOFE_E_NOMEM; }
     memset(p, 0, sizeof(*p));
     p->slots = slots; p->height = height; p->width = width;
     p->win_w = win_w; p->win_h = win_h; p->with_deriv = with_deriv ? 1 : 0;
@@ -109,7 +121,6 @@ int vofe_pyramid_create(vofe_ctx* ctx, int slots, int height, int width, int win
         if (w <= win_w || h <= win_h) break;
     }
     p->levels = n;
-    VOFE_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc((void**)&p->d_I, (size_t)total + 256);
     if (e != hipSuccess) { delete p; return vofe_hip_fail(e, "hipMalloc(pyramid images)"); }
     hipMemsetAsync(p->d_I, 0, (size_t)total + 256, ctx->stream);
@@ -152,6 +163,7 @@ int vofe_pyramid_build(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, const
     }
     if (pitch < pyr->width) { vofe_set_error("vofe_pyramid_build: pitch %d < width %d", pitch, pyr->width); return VOFE_E_ARG; }
     if (count > 65535) { vofe_set_error("vofe_pyramid_build: count %d > 65535", count); return VOFE_E_UNSUPPORTED; }
+    VOFE_BIND(ctx);
     return vofe_launch_pyramid(ctx, pyr, slot0, count, d_img, pitch, img_stride);
 }
 
@@ -172,6 +184,7 @@ int vofe_pyramid_download_padded(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, i
         return VOFE_E_ARG;
     }
     const VofeLevel& L = pyr->lv[level];
+    VOFE_BIND(ctx);
     VOFE_HIP(hipStreamSynchronize(ctx->stream));
     const uint8_t* src = L.I + (long long)slot * L.slot_stride - (long long)pad_y * L.pitch - pad_x;
     const size_t wbytes = (size_t)L.w + 2 * pad_x;
@@ -186,6 +199,7 @@ int vofe_pyramid_download(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int leve
         return VOFE_E_ARG;
     }
     const VofeLevel& L = pyr->lv[level];
+    VOFE_BIND(ctx);
     VOFE_HIP(hipStreamSynchronize(ctx->stream));
     if (h_image)
         VOFE_HIP(hipMemcpy2D(h_image, (size_t)L.w, L.I + (long long)slot * L.slot_stride, (size_t)L.pitch, (size_t)L.w,
@@ -232,6 +246,7 @@ int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
                   int flags, double min_eig_thr) {
     int rc = lk_common("vofe_lk_track", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 0);
     if (rc || n == 0) return rc;
+    VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
     return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
                           max_count, eps, flags, (float)min_eig_thr, 0, 0.f);
@@ -243,6 +258,7 @@ int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
                   double min_eig_thr, float fb_thresh) {
     int rc = lk_common("vofe_track_fb", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 1);
     if (rc || n == 0) return rc;
+    VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
     return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
                           max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
@@ -271,6 +287,7 @@ int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height
     int rc = corner_args("vofe_corner_score", ctx, d_img, height, width, pitch, block_size, aperture);
     if (rc) return rc;
     if (!d_score || batch <= 0) { vofe_set_error("vofe_corner_score: NULL score buffer or batch <= 0"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
     return vofe_launch_corner_score(ctx, d_img, batch, height, width, pitch, img_stride, harris, (float)k, d_score, nullptr, nullptr);
 }
 
@@ -287,6 +304,7 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
     int rc = corner_args("vofe_gftt", ctx, d_img, height, width, pitch, block_size, aperture);
     if (rc) return rc;
     if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt: bad output buffer"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
                           d_corners_xy, capacity, h_n_out);
 }
@@ -304,6 +322,7 @@ int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, i
     int rc = corner_args("vofe_gftt_host", ctx, d_img, height, width, pitch, block_size, aperture);
     if (rc) return rc;
     if (capacity <= 0 || !d_corners_xy) { vofe_set_error("vofe_gftt_host: bad output buffer"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
                           d_corners_xy, capacity, h_n_out, h_corners_xy);
 }
@@ -321,6 +340,7 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
     int rc = corner_args("vofe_gftt_batch", ctx, d_img, height, width, pitch, block_size, aperture);
     if (rc) return rc;
     if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt_batch: bad output buffer"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, batch, height, width, pitch, img_stride, max_corners, quality, min_distance, nullptr,
                           harris, k, d_corners_xy, capacity, h_n_out);
 }
@@ -333,6 +353,7 @@ int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_featu
         vofe_set_error("vofe_new_feature_mask: NULL buffer");
         return VOFE_E_ARG;
     }
+    VOFE_BIND(ctx);
     return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_xy, n_existing, threshold, d_mask);
 }
 
@@ -354,6 +375,7 @@ int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_
         vofe_set_error("vofe_candidate_filter: NULL buffer");
         return VOFE_E_ARG;
     }
+    VOFE_BIND(ctx);
     int rc = vofe_launch_candidate_filter(ctx, d_tracked_xy, d_status, d_first_xy, first_is_f64, d_transform, transform_dim, n,
                                           dist_min, dist_max, dist_triangulate, d_tracked_out, d_first_out, d_transform_out,
                                           d_triangulate_out, d_count_out);
@@ -377,6 +399,7 @@ int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* 
         vofe_set_error("vofe_triangulate_candidates: NULL buffer");
         return VOFE_E_ARG;
     }
+    VOFE_BIND(ctx);
     return vofe_launch_triangulate(ctx, d_K, d_pose, d_cur_xy, d_first_xy, first_is_f64, d_transform, transform_dim, d_flag_in, n,
                                    alpha_min, d_flag_out, d_xyz);
 }
