@@ -47,6 +47,32 @@ def test_pyramid_and_scharr_bit_exact(fe, monkeypatch, h, w, win, levels, path):
     pyr.free()
 
 
+@pytest.mark.parametrize("kernel", ["default", "generic"])
+def test_level0_copy_kernels_around_the_width_limit(fe, monkeypatch, kernel):
+    """The level-0 copy has a divergence-free kernel for frames of at least 16*ceil(win/16)+17 columns and an
+    any-width one below that (VOFE_PAD_COPY=generic forces the latter): both, on widths around the limit, around
+    multiples of 16, and with windows of 1 to 3 mirrored groups per side."""
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    monkeypatch.setenv("VOFE_PYRAMID", "levels")
+    if kernel == "generic":
+        monkeypatch.setenv("VOFE_PAD_COPY", "generic")
+    rng = np.random.default_rng(5)
+    for win in ((5, 5), (21, 21), (16, 9), (33, 12), (40, 40)):
+        for w in (41, 48, 49, 50, 63, 64, 65, 80, 81, 95, 96, 97, 200):
+            if w <= win[0]:
+                continue
+            h = int(rng.integers(win[1] + 1, 70))
+            img = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+            pyr = Pyramid(fe, 2, h, w, win, 0, False)
+            pyr.build(torch.from_numpy(img).cuda(), 0)
+            for slot in range(2):
+                pad = pyr.download_padded(slot, 0)
+                exp = np.pad(img[slot], ((win[1], win[1]), (win[0], win[0])), mode="reflect")
+                assert np.array_equal(pad, exp), (win, w, h, slot)
+            pyr.free()
+
+
 def test_pyramid_large_frame_default_path(fe):
     """Above 3 Mpx per build the per-level kernels are chosen by default (6 levels also exceed the fused plan)."""
     import torch

@@ -61,6 +61,36 @@ __global__ __launch_bounds__(256) void pad_copy_level0(const uint8_t* __restrict
     *reinterpret_cast<uint4*>(d) = mirror16(s + (size_t)sy * spitch, x0, L.w);
 }
 
+// The same for frames at least 16 * max(nl, nr) + 17 pixels wide (every frame but toy sizes), without divergence: a
+// padded row is nl mirrored groups left of the image, ni image groups of which the last is shifted left to end
+// at the last pixel (it overlaps its neighbour with equal bytes), and nr mirrored groups starting right after
+// the last pixel.  Every thread is then one 16-byte load, an optional byte reversal and one 16-byte store
+// (unaligned for the shifted and the right-hand groups); no group straddles an image edge.
+__device__ __forceinline__ void store16(uint8_t* p, uint4 v) {
+    u32x4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    *reinterpret_cast<__attribute__((address_space(1))) u32x4_unaligned*>((__attribute__((address_space(1))) uint8_t*)p) = q;
+}
+__global__ __launch_bounds__(256) void pad_copy_level0_wide(const uint8_t* __restrict__ src, int spitch,
+                                                            size_t img_stride, VofeLevel L, int slot0,
+                                                            int win_h, int nl, int ni, int nr, int items) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int ngx = nl + ni + nr;
+    const int row = it / ngx, g = it - row * ngx;
+    const int y = row - win_h;
+    const int sy = vofe_reflect101(y, L.h);
+    const uint8_t* srow = src + (size_t)blockIdx.y * img_stride + (size_t)sy * spitch;
+    uint8_t* drow = L.I + (long long)(slot0 + (int)blockIdx.y) * L.slot_stride + (long long)y * L.pitch;
+    const int jr = g - nl - ni;                                    // >= 0: right-hand group
+    const bool rev = g < nl || jr >= 0;
+    const int dx = g < nl ? -16 * (nl - g) : (jr >= 0 ? L.w + 16 * jr : min(16 * (g - nl), L.w - 16));
+    const int sx = g < nl ? -dx - 15 : (jr >= 0 ? L.w - 17 - 16 * jr : dx);   // mirrored: out[i] = src[sx + 15 - i]
+    uint4 v = load16(srow + sx);
+    const uint4 r = reversed16(v);
+    if (rev) v = r;
+    store16(drow + dx, v);       // (two rows per thread for more loads in flight measured the same)
+}
+
 // ---------------------------------------------------------------------------------------------
 // pyrDown: interior of the next level plus its two REFLECT_101 border columns on either side.
 // One thread = 8 consecutive output pixels of TWO output rows (7 source rows instead of 10).  A source row
@@ -428,12 +458,22 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     }
     {
         const VofeLevel& L = pyr->lv[0];
-        const int gx0 = fdiv(-ww, 16), gx1 = fdiv(L.w + ww - 1, 16);
-        const int ngx = gx1 - gx0 + 1;
-        const long long items = (long long)ngx * (L.h + 2 * wh);
-        if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
-        hipLaunchKernelGGL(pad_copy_level0, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img, pitch,
-                           img_stride, L, slot0, wh, gx0, ngx, (int)items);
+        const int nb = (ww + 15) / 16;                              // mirrored groups per side
+        const char* pc = getenv("VOFE_PAD_COPY");                   // "generic" forces the any-width kernel (tests)
+        if (L.w >= 16 * nb + 17 && !(pc && pc[0] == 'g')) {
+            const int ni = (L.w + 15) / 16;
+            const long long items = (long long)(2 * nb + ni) * (L.h + 2 * wh);
+            if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+            hipLaunchKernelGGL(pad_copy_level0_wide, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img,
+                               pitch, img_stride, L, slot0, wh, nb, ni, nb, (int)items);
+        } else {
+            const int gx0 = fdiv(-ww, 16), gx1 = fdiv(L.w + ww - 1, 16);
+            const int ngx = gx1 - gx0 + 1;
+            const long long items = (long long)ngx * (L.h + 2 * wh);
+            if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+            hipLaunchKernelGGL(pad_copy_level0, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img, pitch,
+                               img_stride, L, slot0, wh, gx0, ngx, (int)items);
+        }
     }
     for (int l = 1; l < pyr->levels; ++l) {
         const VofeLevel& S = pyr->lv[l - 1];
