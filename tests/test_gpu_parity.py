@@ -23,11 +23,14 @@ def _seq(h, w, seed, n=2):
 @pytest.mark.parametrize("h,w,win,levels", [(376, 1241, (21, 21), 3), (97, 131, (11, 11), 3),
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
                                             (33, 250, (5, 7), 2)])
-@pytest.mark.parametrize("path", ["fused", "levels"])
+@pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic"])
 def test_pyramid_and_scharr_bit_exact(fe, monkeypatch, h, w, win, levels, path):
-    """Both build paths (one fused launch for small frames, per-level kernels for large ones)."""
+    """Both build paths (one fused launch for small frames, per-level kernels for large ones), each with the
+    divergence-free copy / border kernels where the levels are wide enough and with the any-width ones forced."""
     import torch
-    monkeypatch.setenv("VOFE_PYRAMID", path)
+    monkeypatch.setenv("VOFE_PYRAMID", path.split("-")[0])
+    if path.endswith("generic"):
+        monkeypatch.setenv("VOFE_PAD_COPY", "generic")
     from visual_odometry_amd.frontend import Pyramid
     imgs = _seq(h, w, seed=h + w, n=2)
     pyr = Pyramid(fe, 2, h, w, win, levels, True)

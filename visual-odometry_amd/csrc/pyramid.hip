@@ -399,6 +399,48 @@ __global__ __launch_bounds__(256) void pyramid_borders(const VofeLevel* __restri
     *reinterpret_cast<uint4*>(base + (long long)y * L.pitch + x0) = mirror16(srow, x0, L.w);
 }
 
+// The same when every level is at least 16 * nl + 17 pixels wide, laid out like pad_copy_level0_wide: nl mirrored
+// groups left of the image, the image groups (band rows only; the last one shifted to end at the last pixel), nl
+// mirrored groups starting right after the last pixel.  No group straddles an image edge, so no thread gathers bytes.
+struct BorderPlanW {
+    int blk_start[VOFE_MAX_LEVELS + 1];
+    int levels;
+};
+__global__ __launch_bounds__(256) void pyramid_borders_wide(const VofeLevel* __restrict__ lv, BorderPlanW plan, int slot0,
+                                                            int win_w, int win_h) {
+    int level = 0;
+    while (level + 1 < plan.levels && (int)blockIdx.x >= plan.blk_start[level + 1]) ++level;
+    const VofeLevel L = lv[level];
+    const int nl = (win_w + 15) / 16, ni = (L.w + 15) / 16, ng = 2 * nl + ni;
+    int t = ((int)blockIdx.x - plan.blk_start[level]) * 256 + (int)threadIdx.x;
+    int y, g;
+    const int nband = 2 * win_h * ng;
+    if (t < nband) {
+        const int row = t / ng;
+        g = t - row * ng;
+        y = row < win_h ? row - win_h : L.h + (row - win_h);
+    } else {
+        t -= nband;
+        y = t / (2 * nl);
+        if (y >= L.h) return;
+        const int k = t - y * 2 * nl;
+        g = k < nl ? k : k + ni;
+    }
+    uint8_t* base = L.I + (long long)(slot0 + (int)blockIdx.y) * L.slot_stride;
+    const uint8_t* srow = base + (long long)vofe_reflect101(y, L.h) * L.pitch;
+    const int jr = g - nl - ni;                                    // >= 0: right-hand group
+    const bool rev = g < nl || jr >= 0;
+    const int dx = g < nl ? -16 * (nl - g) : (jr >= 0 ? L.w + 16 * jr : min(16 * (g - nl), L.w - 16));
+    const int sx = g < nl ? -dx - 15 : (jr >= 0 ? L.w - 17 - 16 * jr : dx);   // mirrored: out[i] = src[sx + 15 - i]
+    uint4 v = load16(srow + sx);
+    const uint4 r = reversed16(v);
+    if (rev) v = r;
+    store16(base + (long long)y * L.pitch + dx, v);
+}
+
+// Launches the border kernel for levels first_level.. (the wide one when every such level is wide enough).
+void launch_borders(const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st);
+
 BorderPlan border_plan(const vofe_pyr* pyr, int first_level, int* total_blocks) {
     BorderPlan plan;
     plan.levels = pyr->levels;
@@ -418,6 +460,29 @@ BorderPlan border_plan(const vofe_pyr* pyr, int first_level, int* total_blocks) 
 }
 
 inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }   // floor division
+
+void launch_borders(const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st) {
+    const int ww = pyr->win_w, wh = pyr->win_h, nl = (ww + 15) / 16;
+    const char* pc = getenv("VOFE_PAD_COPY");                       // "generic" forces the any-width kernels (tests)
+    bool wide = !(pc && pc[0] == 'g');
+    for (int l = first_level; l < pyr->levels; ++l) wide = wide && pyr->lv[l].w >= 16 * nl + 17;
+    int total = 0;
+    if (wide) {
+        BorderPlanW plan;
+        plan.levels = pyr->levels;
+        for (int l = 0; l < pyr->levels; ++l) {
+            plan.blk_start[l] = total;
+            if (l < first_level) continue;
+            const long long ng = 2 * nl + (pyr->lv[l].w + 15) / 16;
+            total += (int)((2ll * wh * ng + 2ll * nl * pyr->lv[l].h + 255) / 256);
+        }
+        plan.blk_start[pyr->levels] = total;
+        if (total > 0) hipLaunchKernelGGL(pyramid_borders_wide, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
+    } else {
+        const BorderPlan plan = border_plan(pyr, first_level, &total);
+        if (total > 0) hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
+    }
+}
 
 }  // namespace
 
@@ -449,9 +514,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         if (grid.y > 65535) { vofe_set_error("pyramid: image too tall"); return VOFE_E_UNSUPPORTED; }
         hipLaunchKernelGGL(pyramid_fused, grid, dim3(1024), (size_t)off, st, d_img, pitch, img_stride, pyr->d_lv, P, slot0,
                            pyr->with_deriv);
-        int total = 0;
-        const BorderPlan plan = border_plan(pyr, 0, &total);
-        hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
+        launch_borders(pyr, 0, slot0, count, st);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");
         return VOFE_OK;
@@ -484,9 +547,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     }
     if (pyr->levels > 1) {
         // border bands of levels 1.. (level 0 got its border from pad_copy_level0: no blocks for it)
-        int total = 0;
-        const BorderPlan plan = border_plan(pyr, 1, &total);
-        hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
+        launch_borders(pyr, 1, slot0, count, st);
     }
     if (pyr->with_deriv) {
         ScharrPlan plan;
