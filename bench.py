@@ -60,6 +60,8 @@ def main():
                     help="independent frame pairs per step: one pyramid launch set + one LK launch for all of them")
     ap.add_argument("--streams", type=int, default=2,
                     help="steps in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial steps")
+    ap.add_argument("--free-overlap", action="store_true",
+                    help="do not order the LK launches of different streams (they then share the CUs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -108,10 +110,14 @@ def main():
     NB = n * B
     d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 
+    lk_chain = [None]                                       # completion event of the most recent LK launch (any stream)
+
     class Worker:
         """A ctx bound to its own HIP stream with its own pyramid object (2*slots images) and outputs."""
         def __init__(self, stream, pairs):
             self.stream, self.pairs = stream, pairs
+            self.k = 0
+            self.lk_done = [torch.cuda.Event() for _ in range(4)]
             with torch.cuda.stream(stream):
                 self.fe = FrontEnd(local_rank)
                 self.pyr = Pyramid(self.fe, 2 * pairs, H, W, WIN, MAX_LEVEL, True)
@@ -124,6 +130,10 @@ def main():
             imgs, pts, _ = phases[f]
             c = self.fe.ctx
             _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 2 * B, imgs.data_ptr(), W, img_stride))
+            # LK launches of different streams run one after the other (two VALU-bound launches sharing the CUs gain
+            # nothing); the bandwidth-bound pyramid kernels of one stream overlap the LK launch of the other
+            if lk_chain[0] is not None:
+                self.stream.wait_event(lk_chain[0])
             if ev is not None:
                 ev[0].record(self.stream)
             _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, B, pts.data_ptr(), d_idx.data_ptr(),
@@ -131,6 +141,11 @@ def main():
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
             if ev is not None:
                 ev[1].record(self.stream)
+            if args.streams > 1 and not args.free_overlap:
+                done = self.lk_done[self.k % len(self.lk_done)]
+                self.k += 1
+                done.record(self.stream)
+                lk_chain[0] = done
 
         def step_one(self, t):
             # one pair, strictly serial (latency figure)

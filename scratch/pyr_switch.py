@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo')
 from visual_odometry_amd import synthetic, _lib
 from visual_odometry_amd.frontend import FrontEnd, Pyramid
 fe = FrontEnd(0); L = fe.L
-for name, counts in (("kitti", (1, 2, 4, 6, 8, 16, 32)), ("malaga", (1, 2, 4)), ("stress", (1, 2))):
+for name, counts in (("kitti", (1, 2, 4, 5, 6, 8, 16, 32)), ("malaga", (1, 2, 4, 5, 6)), ("stress", (1, 2))):
     H, W, seed, n, win, lvl = synthetic.CONFIGS[name]
     a, b = synthetic.sequence(H, W, seed, 2)
     for B in counts:

@@ -77,7 +77,7 @@ def test_level0_copy_kernels_around_the_width_limit(fe, monkeypatch, kernel):
 
 
 def test_pyramid_large_frame_default_path(fe):
-    """Above 3 Mpx per build the per-level kernels are chosen by default (6 levels also exceed the fused plan)."""
+    """Above 2 Mpx per build the per-level kernels are chosen by default (6 levels also exceed the fused plan)."""
     import torch
     from visual_odometry_amd.frontend import Pyramid
     h, w = 1300, 2500

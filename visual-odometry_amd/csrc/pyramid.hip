@@ -494,7 +494,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     // Large frames are bandwidth bound and the halo recompute of the fused kernel costs more than the extra
     // launches (3840x2160 pair: 134 us fused vs 77 us per-level), so they take the per-level kernels.
     const char* force = getenv("VOFE_PYRAMID");          // "fused" / "levels" force one path (tests, measurements)
-    const bool small = (long long)pyr->height * pyr->width * count <= 3000000ll;
+    const bool small = (long long)pyr->height * pyr->width * count <= 2000000ll;      // measured cross-over (scratch/pyr_switch.py)
     const bool fused = force ? force[0] == 'f' : small;
     if (pyr->levels <= FUSE_MAX_LEVELS && fused) {
         // fused path: 2 launches (interiors + Scharr, then border bands)
