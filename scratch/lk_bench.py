@@ -5,7 +5,10 @@ import oracle
 from visual_odometry_amd import synthetic, _lib
 from visual_odometry_amd.frontend import FrontEnd, Pyramid
 cfg = sys.argv[1] if len(sys.argv) > 1 else "kitti"
+import os
 H, W, seed, n, win, lvl = synthetic.CONFIGS[cfg]
+if os.environ.get("LKB_WIN"): win = (int(os.environ["LKB_WIN"]),) * 2       # overrides for what-if runs
+if os.environ.get("LKB_N"): n = int(os.environ["LKB_N"])
 fe = FrontEnd(0); L = fe.L
 a, b = synthetic.sequence(H, W, seed, 2)
 d = torch.from_numpy(np.stack([a, b])).cuda()
@@ -28,4 +31,9 @@ for name, fn in (("pyramid x2", build), ("lk fwd+bwd", lk)):
     torch.cuda.synchronize()
     ts = sorted(x.elapsed_time(y) for x, y in ev)
     print("%s: median %.1f us  min %.1f us" % (name, ts[50] * 1e3, ts[0] * 1e3))
+cnt = torch.zeros(3, dtype=torch.int64, device="cuda")
+_lib.check(L.vofe_lk_set_counters(fe.ctx, cnt.data_ptr())); lk(); torch.cuda.synchronize()
+_lib.check(L.vofe_lk_set_counters(fe.ctx, None))
+c = cnt.cpu().numpy()
+print("points %d: %.2f level passes per point, %.2f Gauss-Newton iterations per level pass" % (n, c[1] / n, c[2] / max(c[1], 1)))
 fe.close()

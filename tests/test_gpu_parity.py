@@ -174,6 +174,41 @@ def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
 
 
+@pytest.mark.parametrize("win", [11, 31])
+@pytest.mark.parametrize("kernel", ["default", "generic"])
+def test_lk_ragged_compile_time_windows(fe, monkeypatch, win, kernel):
+    """11x11 (the reference's Parking window) and 31x31 run compile-time-geometry kernels whose last row group is
+    ragged (3+3+3+2 and 16+15 rows); the run-time-geometry kernel (VOFE_LK=generic) must agree with them and the
+    oracle on tracking, flags, wild points, flat frames and extreme contrast."""
+    if kernel == "generic":
+        monkeypatch.setenv("VOFE_LK", "generic")
+    a, b = _seq(240, 320, 21)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 21)
+    for lvl in (3, 0):
+        exact, _, st = _lk_compare(fe, a, b, pts, (win, win), lvl)
+        assert exact and st.sum() > 200
+    init = (pts + np.float32([1.0, 0.5])).astype(np.float32)
+    assert _lk_compare(fe, a, b, pts, (win, win), 2, flags=4, init=init)[0]
+    assert _lk_compare(fe, a, b, pts, (win, win), 2, flags=8, min_eig=1e-3)[0]
+    t1 = fe.track_keypoints(pts.T, a, b, winSize=(win, win))
+    t0 = oracle.track_keypoints(pts.T, a, b, winSize=(win, win), nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
+    wild = np.float32([[-30, 5], [5, -30], [400, 50], [50, 400], [-5.5, -5.5], [319.9, 239.9], [0, 0],
+                       [80, 60], [np.nan, 3], [1e12, 1e12], [-1e20, 4], [np.inf, 0], [100, 100]])
+    flat = np.full_like(a, 77)
+    for (x, y) in ((a, b), (flat, flat), (a, flat)):
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(x, y, wild, None, (win, win), 2)
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(x, y, wild, None, (win, win), 2)
+        assert np.array_equal(s0, s1) and np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True)
+    rng = np.random.default_rng(18)
+    hc = np.kron((rng.random((60, 80)) > 0.5).astype(np.uint8) * 255, np.ones((4, 4), np.uint8))
+    hd = np.roll(hc, (1, 2), axis=(0, 1))
+    p2 = (rng.random((301, 2)) * [319, 239]).astype(np.float32)
+    n0, s0, e0 = oracle.calcOpticalFlowPyrLK(hc, hd, p2, None, (win, win), 2, (3, 30, 0.01), 0, 1e-4, nthreads=8)
+    n1, s1, e1 = fe.calcOpticalFlowPyrLK(hc, hd, p2, None, (win, win), 2, (3, 30, 0.01), 0, 1e-4)
+    assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
+
+
 @pytest.mark.parametrize("ppw", ["x2", "x4"])
 def test_lk_several_keypoints_per_wavefront_kernel(fe, monkeypatch, ppw):
     """Large 21x21 launches take the kernel that packs several keypoints into one wavefront; forced here on

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Secondary measurements for BASELINE.json configs[2..4] (bench.py covers configs[1]).
+"""Secondary measurements for BASELINE.json configs[2..4] and a synthetic frame of configs[0]'s shape (Parking 640x480,
+11x11 window, 1000 points; the real sequence and cv2 are not in the image) -- bench.py covers configs[1].
 
 Front-end frame = what one process_frame asks of the feature front end: forward-backward
 tracking of the frame's points + goodFeaturesToTrack on the new frame.  Reported device-resident
@@ -121,7 +122,8 @@ def sequences_64(fe, reps):
 
 def main():
     fe = FrontEnd(0)
-    res = [front_end_frame(fe, "malaga", 10, 100), front_end_frame(fe, "stress", 10, 20), sequences_64(fe, 8)]
+    res = [front_end_frame(fe, "parking", 10, 100), front_end_frame(fe, "malaga", 10, 100), front_end_frame(fe, "stress", 10, 20),
+           sequences_64(fe, 8)]
     fe.close()
     for r in res:
         print(json.dumps(r), flush=True)

@@ -216,9 +216,10 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
 constexpr int LK_X2_MIN_POINTS = 4000;     // measured (scratch/lk_threshold.py, lk_bench.py): one per wavefront 5 % ahead at 3000 points, two per wavefront 8 % ahead at 4000
 constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
 
-// WC != 0: compile-time square window WC x WC with R * groups == WC (every active lane owns exactly R rows;
-// idle lanes sit on row 0 with ny == 0), so window geometry, the LDS row stride and all row offsets fold to
-// constants (LDS reads take immediate offsets).  WC == 0: everything at run time, ragged last group allowed.
+// WC != 0: compile-time square window WC x WC, so window geometry, the LDS row stride and all row offsets fold
+// to constants (LDS reads take immediate offsets).  When R divides WC the mapping is regular (REG): every active
+// lane owns exactly R rows and idle lanes sit on row 0 with ny == 0; otherwise the last row group is ragged and
+// rows are clamped / masked per lane as in the run-time case.  WC == 0: everything at run time.
 template <int R, int WC>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
@@ -226,6 +227,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                                        int ny, unsigned& n_lv, unsigned& n_it, unsigned long long* st_acc) {
     STAMP_DECL
     (void)st_acc;
+    constexpr bool REG = WC != 0 && WC % R == 0;
+    constexpr bool WIDE = WC == 21;                  // 12-byte staging loads: measured slower on the larger windows
     const int w = WC ? WC : a.win_w, h = WC ? WC : a.win_h;
     const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
     const int top = a.n_levels - 1;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
     const int segs = WC ? SEGS_C : a.segs, rs = 8 * segs;
     const int inv_segs = WC ? (1 << 20) / SEGS_C + 1 : a.inv_segs;
     const int tasks = (WC ? WC + 1 + 2 * LK_MARGIN : a.rh) * segs;
-#define LK_ROW(r) (WC ? (r) : min((r), ny))
+#define LK_ROW(r) (REG ? (r) : min((r), ny))
     for (int level = top; level >= 0; --level) {
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
@@ -278,7 +281,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const unsigned off0 = (unsigned)(y0 * A.pitch + x);
             unsigned pI[R + 1];
             unsigned pX[R + 1], pY[R + 1];     // (Ix[x] | Ix[x+1] << 16), (Iy[x] | Iy[x+1] << 16)
-            if (staged) stage_load<WC != 0>(pre, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+            if (staged) stage_load<WIDE>(pre, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
 #pragma unroll
             for (int r = 0; r <= R; ++r) {
                 const unsigned off = off0 + (unsigned)(LK_ROW(r) * A.pitch);
@@ -291,13 +294,13 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             int a11 = 0, a12 = 0, a22 = 0;
             // rows a lane does not own must contribute Ix = Iy = 0.  With the regular mapping (WC) a lane owns
             // all R rows or none, so zero weights do it: (0 + 8192) >> 14 == 0.
-            const unsigned dw0 = (WC && ny == 0) ? 0u : q.w0, dw1 = (WC && ny == 0) ? 0u : q.w1;
+            const unsigned dw0 = (REG && ny == 0) ? 0u : q.w0, dw1 = (REG && ny == 0) ? 0u : q.w1;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
                 int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
                 int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
-                if (!WC && k >= ny) { ix = 0; iy = 0; }
+                if (!REG && k >= ny) { ix = 0; iy = 0; }
                 Ival[k] = iv;
                 Dval[k] = (ix & 0xffff) | (iy << 16);
                 a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
@@ -325,7 +328,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         if (staged) {
             __syncthreads();
             stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
-            stage_rest<WC != 0>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
+            stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
             __syncthreads();
         }
         STAMP_END(2);
@@ -338,7 +341,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_rest<WC != 0>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
@@ -389,7 +392,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
                 __syncthreads();
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_rest<WC != 0>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
                 staged = true;
                 __syncthreads();
             }
@@ -403,9 +406,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             for (int k = 0; k < R; ++k) {
                 const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
                 const int diff = jv - Ival[k];
-                se += (WC || k < ny) ? abs(diff) : 0;
+                se += (REG || k < ny) ? abs(diff) : 0;
             }
-            if (WC && ny == 0) se = 0;
+            if (REG && ny == 0) se = 0;
             err = wave_sum_to_float(se) / (float)(32 * w * h);
         }
         __syncthreads();     // all LDS reads of this level done before the next level restages
@@ -423,9 +426,11 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     const int ww = WC ? WC : a.win_w, wh = WC ? WC : a.win_h;
     const int g = lane / ww;
     const int x = lane - g * ww;
-    const bool active = g < (WC ? WC / R : a.groups);
-    const int y0 = WC ? (active ? g * R : 0) : min(g * a.rows_per_group, wh);
-    const int ny = WC ? (active ? R : 0) : (active ? min(a.rows_per_group, wh - y0) : 0);
+    constexpr bool REG = WC != 0 && WC % R == 0;
+    const int rpg = WC ? R : a.rows_per_group;
+    const bool active = g < (WC ? (WC + R - 1) / R : a.groups);
+    const int y0 = REG ? (active ? g * R : 0) : min(g * rpg, wh);
+    const int ny = REG ? (active ? R : 0) : (active ? min(rpg, wh - y0) : 0);
 
     const float2 p = a.prev_pts[i];
     const int idx = a.img_idx ? a.img_idx[i] : 0;
@@ -855,6 +860,10 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
         hipLaunchKernelGGL(lk_track_kernel_x2<2>, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
+    // the other windows the reference uses (constants.py:49 Parking 11x11) and the stress configuration's 31x31:
+    // compile-time geometry with a ragged last row group (4 x 3 rows for 11, 16 + 15 rows for 31)
+    else if (a.win_w == 11 && a.win_h == 11 && !(force && force[0] == 'g')) launch_r<3, 11>(a, lds_bytes, st);
+    else if (a.win_w == 31 && a.win_h == 31 && !(force && force[0] == 'g')) launch_r<16, 31>(a, lds_bytes, st);
     else if (R <= 2) launch_r<2>(a, lds_bytes, st);
     else if (R <= 3) launch_r<3>(a, lds_bytes, st);
     else if (R <= 4) launch_r<4>(a, lds_bytes, st);
