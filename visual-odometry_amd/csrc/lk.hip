@@ -708,7 +708,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             outx = npx + hx; outy = npy + hy;
             const float d2 = dx * dx + dy * dy;
             bool conv = d2 < a.eps2_lo;
-            if (!conv && !(d2 > a.eps2_hi)) conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
+            if (__any(!conv && !(d2 > a.eps2_hi)))          // ballot: keeps the f64 sequence out of the common path
+                conv = conv || (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
             if (conv) break;
             if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
