@@ -913,24 +913,29 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 1), 1), SELECT_ROUNDS);
     static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 2), 1);
     static const int sel_spins = std::max(env_int("VOFE_SEL_SPINS", 64), 0);
-    static const int sel_prefix = std::max(env_int("VOFE_SEL_PREFIX", 2), 1);
-    // Lists up to sel_full times the first prefix are taken whole (VOFE_SEL_FULL overrides).  Default: twice - unless the
-    // request is close to what the frame can hold at all.  Accepted corners pack to about one per 1.7 * minDistance^2
-    // pixels on densely textured frames (measured: 5366 on 1241x376 at 7 px, 2868 on 800x600 at 10 px); a request
-    // beyond ~0.6 of that capacity will need most of the list anyway, and starting with all of it saves the second
-    // selection pass (800x600, 3000 corners at 10 px: 122 us against 163 us; 1241x376, 2000 corners at 7 px needs only
-    // the first prefix: 80 us against 105 us for the whole list).
-    static const int sel_full_env = env_int("VOFE_SEL_FULL", 0);
+    static const int sel_prefix_env = env_int("VOFE_SEL_PREFIX", 0);       // > 0: fixed first-prefix factor (tests, tuning)
+    static const int sel_full_env = env_int("VOFE_SEL_FULL", 0);           // > 0: fixed whole-list ratio
+    // How many of the best-ranked candidates hold maxCorners accepted ones?  On densely textured frames the accepted
+    // corners saturate at about one per 1.7 * minDistance^2 pixels (capacity C; measured 5366 on 1241x376 at 7 px, 2868
+    // on 800x600 at 10 px, 1849 on 640x480 at 10 px) and the best K candidates hold about C * (1 - exp(-K / 1.5 C)) of
+    // them (640x480 at 10 px: 915 in the best 2001, 1245 in 4003; 1241x376 at 10 px: 1064 in 2000).  The first prefix
+    // is that K for 1.1 * maxCorners, plus 5 % (growing to 19 % at 0.75 C, where the model is optimistic), and at least 2 * maxCorners; a request beyond 0.75 C, or a list
+    // shorter than twice the prefix, starts with the whole list: a prefix that turns out too short costs a second
+    // selection pass (640x480, 1000 corners at 10 px: 113 us with the former fixed factor of 2, 102 us with the whole
+    // list; 800x600, 3000 corners at 10 px needs the whole list: 122 us against 163 us via a prefix).
+    double prefix_factor = sel_prefix_env > 0 ? (double)sel_prefix_env : 2.0;
     int sel_full = sel_full_env > 0 ? sel_full_env : 2;
-    if (sel_full_env <= 0 && max_corners > 0 && suppress) {
-        const double capacity = (double)h * (double)w / (1.7 * std::max(min_distance, 1.0) * std::max(min_distance, 1.0));
-        if ((double)max_corners >= 0.6 * capacity) sel_full = 1 << 20;
+    if (max_corners > 0 && suppress) {
+        const double capacity = (double)h * (double)w / (1.7 * min_distance * min_distance);
+        const double r = (double)max_corners / capacity;
+        if (sel_full_env <= 0 && r >= 0.75) sel_full = 1 << 20;
+        if (sel_prefix_env <= 0 && r < 0.75) prefix_factor = std::max(2.0, -1.5 / r * std::log(1.0 - 1.1 * r) * (1.05 + 0.4 * std::max(0.0, r - 0.4)));
     }
     // first rank prefix: without suppression the best maxCorners candidates are the answer; with it,
     // a few times maxCorners candidates usually hold maxCorners accepted ones (grown x2 otherwise)
     unsigned seg_base = 0;
     if (max_corners > 0) {
-        const unsigned long long b0 = (unsigned long long)max_corners * (suppress ? sel_prefix : 1);
+        const unsigned long long b0 = suppress ? (unsigned long long)std::ceil((double)max_corners * prefix_factor) : (unsigned long long)max_corners;
         seg_base = (unsigned)std::min<unsigned long long>(b0, 1u << 24);
     }
 
