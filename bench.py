@@ -136,7 +136,7 @@ def main():
                 self.stream.wait_event(lk_chain[0])
             if ev is not None:
                 ev[0].record(self.stream)
-            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, B, pts.data_ptr(), d_idx.data_ptr(),
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, B, pts.data_ptr(), d_idx.data_ptr(), B,
                                        self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), NB,
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
             if ev is not None:
@@ -151,7 +151,7 @@ def main():
             # one pair, strictly serial (latency figure)
             c = self.fe.ctx
             _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 2, d_frames[t].data_ptr(), W, img_stride))
-            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, 1, d_pts[t].data_ptr(), None,
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, 0, self.pyr._h, 1, d_pts[t].data_ptr(), None, 1,
                                        self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
 
@@ -162,7 +162,7 @@ def main():
             if t == 0:
                 _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 1, d_frames[0].data_ptr(), W, 0))
             _lib.check(L.vofe_pyramid_build(c, self.pyr._h, (t + 1) & 1, 1, d_frames[t + 1].data_ptr(), W, 0))
-            _lib.check(L.vofe_track_fb(c, self.pyr._h, t & 1, self.pyr._h, (t + 1) & 1, d_pts[t].data_ptr(), None,
+            _lib.check(L.vofe_track_fb(c, self.pyr._h, t & 1, self.pyr._h, (t + 1) & 1, d_pts[t].data_ptr(), None, 1,
                                        self.nxt.data_ptr(), self.st.data_ptr(), self.err.data_ptr(), n,
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
 

@@ -49,6 +49,10 @@ int vofe_version(void);
 int vofe_create(int device, void* hip_stream, vofe_ctx** out);
 int vofe_destroy(vofe_ctx* ctx);
 int vofe_synchronize(vofe_ctx* ctx);
+/* The VOFE_* environment switches (kernel-path overrides for tests and measurements: VOFE_LK, VOFE_PYRAMID,
+ * VOFE_PAD_COPY, VOFE_CORNER_SCORE, VOFE_SCORE_RS, VOFE_GFTT_SORT, VOFE_GFTT_DEBUG, VOFE_SEL_*) are read once, by
+ * vofe_create; this re-reads them for an existing context (test aid; no counterpart in the reference). */
+int vofe_reload_env(vofe_ctx* ctx);
 
 /* ---- Gaussian pyramid + Scharr derivatives --------------------------------------------------
  * Replaces cv::buildOpticalFlowPyramid + cv::calcScharrDeriv, which cv2.calcOpticalFlowPyrLK runs
@@ -80,11 +84,14 @@ int vofe_pyramid_download_padded(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, i
  * initialization.py:51-52.  prev/next pyramids must have the same geometry and window; maxLevel
  * is the pyramids' level count - 1.  Point i reads slot prev_slot + idx and next_slot + idx with
  * idx = d_img_idx ? d_img_idx[i] : 0, so one launch tracks a ragged batch of independent
- * sequences.  d_prev_pts / d_next_pts are (n,2) f32 xy; d_next_pts is read only with
+ * sequences.  n_images bounds the index: slots prev_slot .. prev_slot + n_images - 1 (and the same
+ * for next) must exist, which is checked; a point whose index lies outside [0, n_images) is reported
+ * lost (status 0, err 0) and never addresses memory outside the batch.  n_images is ignored (1) when
+ * d_img_idx is NULL.  d_prev_pts / d_next_pts are (n,2) f32 xy; d_next_pts is read only with
  * VOFE_OPTFLOW_USE_INITIAL_FLOW.  d_status (n) u8, d_err (n) f32 (entries cv2 leaves
  * uninitialised are written as 0). */
 int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
                   int flags, double min_eig_thr);
 
@@ -94,7 +101,7 @@ int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
  * A keypoint the forward pass loses is not tracked backward: its status is 0 whatever the backward
  * pass would find, and no backward result is returned. */
 int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
                   double min_eig_thr, float fb_thresh);
 
@@ -102,6 +109,15 @@ int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
  * launch of this ctx adds {points, point-levels entered, Gauss-Newton iterations} to the three
  * device uint64 words at d_counters (both passes of vofe_track_fb count).  NULL switches it off. */
 int vofe_lk_set_counters(vofe_ctx* ctx, unsigned long long* d_counters);
+
+/* Measurement aid (no counterpart in the reference): between vofe_profile_begin and vofe_profile_end every kernel this
+ * context launches for the pyramid, Scharr, score-map and detector stages is bracketed by two HIP events on the
+ * context's stream (the stream bench.py's roofline figures must be timed on).  vofe_profile_end synchronises the
+ * stream and returns, in launch order, up to `capacity` kernel names (VOFE_PROFILE_NAME_LEN bytes each, NUL
+ * terminated; pyrDown / per-level kernels carry " L<level>") and their durations in milliseconds. */
+#define VOFE_PROFILE_NAME_LEN 48
+int vofe_profile_begin(vofe_ctx* ctx);
+int vofe_profile_end(vofe_ctx* ctx, int capacity, char* names, float* ms, int* n_out);
 
 /* ---- corner detection --------------------------------------------------------------------------
  * vofe_corner_score replaces cv::cornerMinEigenVal / cv::cornerHarris (blockSize 3, Sobel
@@ -113,9 +129,10 @@ int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height
 
 /* Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
  * useHarrisDetector, k) (reference continuous.py:380-385, initialization.py:41-42).
- * d_corners_xy receives up to `capacity` (x,y) f32 pairs, strongest first; *h_n_out (host) the
- * number of corners cv2 would return (0 == cv2 returning None), which may exceed capacity only
- * when max_corners <= 0.  d_mask may be NULL (u8, height*width, contiguous).
+ * d_corners_xy receives min(*h_n_out, capacity) (x,y) f32 pairs, strongest first; *h_n_out (host) the
+ * number of corners cv2 would return (0 == cv2 returning None): at most max_corners when that is
+ * positive, every accepted corner otherwise -- it exceeds capacity whenever capacity is the smaller.
+ * d_mask may be NULL (u8, height*width, contiguous).
  * Synchronous: returns after the corner count is known. */
 int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
               int max_corners, double quality, double min_distance, const uint8_t* d_mask,

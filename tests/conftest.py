@@ -20,4 +20,30 @@ def fe():
     yield f
     f.close()
 
+
+
+@pytest.fixture
+def knob(fe):
+    """knob(name, value) sets a VOFE_* switch for one test, knob(name) clears it.  The library reads the switches once
+    per context (vofe_create), so the session's context re-reads them after every change and at the end of the test."""
+    saved = {}
+
+    def set_(name, value=None):
+        if name not in saved:
+            saved[name] = os.environ.get(name)
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        fe.reload_env()
+
+    yield set_
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    fe.reload_env()
+
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

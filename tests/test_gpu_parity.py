@@ -24,13 +24,13 @@ def _seq(h, w, seed, n=2):
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
                                             (33, 250, (5, 7), 2)])
 @pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic"])
-def test_pyramid_and_scharr_bit_exact(fe, monkeypatch, h, w, win, levels, path):
+def test_pyramid_and_scharr_bit_exact(fe, knob, h, w, win, levels, path):
     """Both build paths (one fused launch for small frames, per-level kernels for large ones), each with the
     divergence-free copy / border kernels where the levels are wide enough and with the any-width ones forced."""
     import torch
-    monkeypatch.setenv("VOFE_PYRAMID", path.split("-")[0])
+    knob("VOFE_PYRAMID", path.split("-")[0])
     if path.endswith("generic"):
-        monkeypatch.setenv("VOFE_PAD_COPY", "generic")
+        knob("VOFE_PAD_COPY", "generic")
     from visual_odometry_amd.frontend import Pyramid
     imgs = _seq(h, w, seed=h + w, n=2)
     pyr = Pyramid(fe, 2, h, w, win, levels, True)
@@ -51,15 +51,15 @@ def test_pyramid_and_scharr_bit_exact(fe, monkeypatch, h, w, win, levels, path):
 
 
 @pytest.mark.parametrize("kernel", ["default", "generic"])
-def test_level0_copy_kernels_around_the_width_limit(fe, monkeypatch, kernel):
+def test_level0_copy_kernels_around_the_width_limit(fe, knob, kernel):
     """The level-0 copy has a divergence-free kernel for frames of at least 16*ceil(win/16)+17 columns and an
     any-width one below that (VOFE_PAD_COPY=generic forces the latter): both, on widths around the limit, around
     multiples of 16, and with windows of 1 to 3 mirrored groups per side."""
     import torch
     from visual_odometry_amd.frontend import Pyramid
-    monkeypatch.setenv("VOFE_PYRAMID", "levels")
+    knob("VOFE_PYRAMID", "levels")
     if kernel == "generic":
-        monkeypatch.setenv("VOFE_PAD_COPY", "generic")
+        knob("VOFE_PAD_COPY", "generic")
     rng = np.random.default_rng(5)
     for win in ((5, 5), (21, 21), (16, 9), (33, 12), (40, 40)):
         for w in (41, 48, 49, 50, 63, 64, 65, 80, 81, 95, 96, 97, 200):
@@ -93,12 +93,12 @@ def test_pyramid_large_frame_default_path(fe):
 
 
 @pytest.mark.parametrize("path", ["fused", "levels"])
-def test_region_of_interest_views_pitch_and_misaligned_base(fe, monkeypatch, path):
+def test_region_of_interest_views_pitch_and_misaligned_base(fe, knob, path):
     """Callers hand over views: a crop of a larger device image has pitch > width and a base address with no
     alignment at all.  Pyramid, score map, detector and tracker must read exactly the crop."""
     import torch
     from visual_odometry_amd.frontend import Pyramid
-    monkeypatch.setenv("VOFE_PYRAMID", path)
+    knob("VOFE_PYRAMID", path)
     big = _seq(300, 517, seed=9, n=2)
     d_big = torch.from_numpy(np.stack(big)).cuda()
     for (y0, x0, h, w) in ((5, 3, 240, 401), (1, 1, 128, 130), (17, 64, 200, 333)):
@@ -162,9 +162,9 @@ def test_lk_matches_oracle(fe, h, w, seed, win, lvl, npts):
     assert st.sum() > 0.5 * npts
 
 
-def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
+def test_lk_21x21_generic_kernel_path(fe, knob):
     """21x21 windows normally run the compile-time specialisation; the run-time-geometry kernel must agree."""
-    monkeypatch.setenv("VOFE_LK", "generic")
+    knob("VOFE_LK", "generic")
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 400, 0.01, 7), 400, 240, 320, 12)
     exact, _, st = _lk_compare(fe, a, b, pts, (21, 21), 3)
@@ -176,12 +176,12 @@ def test_lk_21x21_generic_kernel_path(fe, monkeypatch):
 
 @pytest.mark.parametrize("win", [11, 31])
 @pytest.mark.parametrize("kernel", ["default", "generic"])
-def test_lk_ragged_compile_time_windows(fe, monkeypatch, win, kernel):
+def test_lk_ragged_compile_time_windows(fe, knob, win, kernel):
     """11x11 (the reference's Parking window) and 31x31 run compile-time-geometry kernels whose last row group is
     ragged (3+3+3+2 and 16+15 rows); the run-time-geometry kernel (VOFE_LK=generic) must agree with them and the
     oracle on tracking, flags, wild points, flat frames and extreme contrast."""
     if kernel == "generic":
-        monkeypatch.setenv("VOFE_LK", "generic")
+        knob("VOFE_LK", "generic")
     a, b = _seq(240, 320, 21)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 21)
     for lvl in (3, 0):
@@ -210,10 +210,10 @@ def test_lk_ragged_compile_time_windows(fe, monkeypatch, win, kernel):
 
 
 @pytest.mark.parametrize("ppw", ["x2", "x4"])
-def test_lk_several_keypoints_per_wavefront_kernel(fe, monkeypatch, ppw):
+def test_lk_several_keypoints_per_wavefront_kernel(fe, knob, ppw):
     """Large 21x21 launches take the kernel that packs several keypoints into one wavefront; forced here on
     small inputs: counts not divisible by the packing, wild points, flags, extreme contrast, FB twin."""
-    monkeypatch.setenv("VOFE_LK", ppw)
+    knob("VOFE_LK", ppw)
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 12)
     for lvl in (3, 0):
@@ -368,10 +368,10 @@ def test_corner_score_bit_exact(fe, h, w, seed, harris):
 
 
 @pytest.mark.parametrize("path", ["strip", "tile"])
-def test_corner_score_kernel_paths_and_edges(fe, monkeypatch, path):
+def test_corner_score_kernel_paths_and_edges(fe, knob, path):
     """Register-strip kernel (w >= 8, h >= 4) and LDS-tile kernel on widths/heights around every
     internal boundary: 4-column threads, 256-column waves, 4/8-row strips, last-column position."""
-    monkeypatch.setenv("VOFE_CORNER_SCORE", path)
+    knob("VOFE_CORNER_SCORE", path)
     rng = np.random.default_rng(3)
     for (h, w) in ((2, 8), (3, 9), (4, 8), (4, 13), (5, 10), (6, 300), (7, 11), (9, 12), (17, 255), (16, 256), (33, 257), (31, 258), (4, 259),
                    (40, 515), (130, 64), (129, 1030)):
@@ -444,9 +444,9 @@ def test_gftt_large_sort(fe):
     assert ref.shape[0] == 20000 and np.array_equal(got, ref)
 
 
-def test_gftt_bitonic_network_forced(fe, monkeypatch):
+def test_gftt_bitonic_network_forced(fe, knob):
     """The rank sort serves up to 32768 corners; the bitonic network behind it must stay exact too."""
-    monkeypatch.setenv("VOFE_GFTT_SORT", "bitonic")
+    knob("VOFE_GFTT_SORT", "bitonic")
     a = _seq(700, 900, 31, 1)[0]
     for args in ((0, 0.0005, 1), (20000, 0.0005, 0), (500, 0.01, 6)):
         assert np.array_equal(fe.goodFeaturesToTrack(a, *args), oracle.goodFeaturesToTrack(a, *args, nthreads=8))
@@ -624,13 +624,13 @@ def test_full_size_config_front_end_frame(fe, cfg, md):
 
 
 @pytest.mark.parametrize("kernel", ["x1", "x2", "x4"])
-def test_ragged_batch_of_sequences_in_one_launch(fe, monkeypatch, kernel):
+def test_ragged_batch_of_sequences_in_one_launch(fe, knob, kernel):
     """configs[3] batching: B pairs in one pyramid object, points of all pairs in ONE launch with a per-point
     image index (ragged: different counts per pair, one pair with none) == the per-pair results."""
     import torch
     from visual_odometry_amd import _lib
     from visual_odometry_amd.frontend import Pyramid
-    monkeypatch.setenv("VOFE_LK", kernel)
+    knob("VOFE_LK", kernel)
     H, W, B = 120, 200, 4
     pairs = [_seq(H, W, 60 + s, 2) for s in range(B)]
     counts = [90, 0, 37, 150]
@@ -645,7 +645,7 @@ def test_ragged_batch_of_sequences_in_one_launch(fe, monkeypatch, kernel):
     nxt = torch.empty((n, 2), dtype=torch.float32, device="cuda")
     st = torch.empty(n, dtype=torch.uint8, device="cuda")
     err = torch.empty(n, dtype=torch.float32, device="cuda")
-    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), idx.data_ptr(), nxt.data_ptr(), st.data_ptr(),
+    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), idx.data_ptr(), B, nxt.data_ptr(), st.data_ptr(),
                                   err.data_ptr(), n, 3, 30, 0.01, 1e-3, 1.0))
     nxt, st, err = nxt.cpu().numpy(), st.cpu().numpy(), err.cpu().numpy()
     o = 0
@@ -657,6 +657,127 @@ def test_ragged_batch_of_sequences_in_one_launch(fe, monkeypatch, kernel):
         assert np.array_equal(nxt[o:o + k].T, t0) and np.array_equal(st[o:o + k], s0) and np.array_equal(err[o:o + k], e0)
         o += k
     pyr.free()
+
+
+def test_bench_launch_shape_default_dispatch_64_pairs(fe):
+    """The launch bench.py times, checked at the shape it is timed at: 64 KITTI-shaped pairs (sequences 100 + s),
+    2000 points each, ONE vofe_pyramid_build of 128 slots and ONE vofe_track_fb of 128 000 points with a per-point
+    image index -- so the size rule (not VOFE_LK) picks lk_track_kernel_x2<2> and the 32-bit slot offsets span a
+    ~290 MB derivative plane set.  Every pair must equal oracle.track_keypoints bit for bit."""
+    import os
+    import torch
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import Pyramid
+    assert not os.environ.get("VOFE_LK")
+    H, W, _, n, win, lvl = synthetic.CONFIGS["kitti"]
+    B = 64
+    pairs = [synthetic.sequence(H, W, seed=100 + s, n_frames=2) for s in range(B)]
+    d_prev = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    d_next = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    det, cnt = fe.goodFeaturesToTrack_batch(d_prev, n, 0.01, 7)
+    det = det.cpu().numpy()
+    pts = [synthetic.pad_points(det[s, :cnt[s]], n, H, W, 100 + s) for s in range(B)]
+    pyr = Pyramid(fe, 2 * B, H, W, win, lvl, True)
+    pyr.build(torch.cat([d_prev, d_next]), 0)
+    allp = torch.from_numpy(np.concatenate(pts)).cuda()
+    idx = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(n).contiguous()
+    N = n * B
+    nxt = torch.empty((N, 2), dtype=torch.float32, device="cuda")
+    st = torch.empty(N, dtype=torch.uint8, device="cuda")
+    err = torch.empty(N, dtype=torch.float32, device="cuda")
+    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), idx.data_ptr(), B, nxt.data_ptr(),
+                                  st.data_ptr(), err.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0))
+    nxt, st, err = nxt.cpu().numpy(), st.cpu().numpy(), err.cpu().numpy()
+    tracked = 0
+    for s in range(B):
+        t0, s0, e0 = oracle.track_keypoints(pts[s].T, pairs[s][0], pairs[s][1], win, lvl, (3, 30, 0.01), 1e-3, 1.0, nthreads=16)
+        o = s * n
+        assert np.mean(st[o:o + n] == s0) >= STATUS_MIN, s
+        ok = (st[o:o + n] == 1) & (s0 == 1)
+        assert np.abs(nxt[o:o + n].T - t0)[:, ok].max() <= POS_TOL, s
+        assert np.array_equal(st[o:o + n], s0) and np.array_equal(nxt[o:o + n].T, t0) and np.array_equal(err[o:o + n], e0), s
+        tracked += int(s0.sum())
+    assert tracked > 0.9 * N
+    # an image index outside [0, n_images) loses the point instead of addressing memory outside the batch, and the
+    # slot range the indices can reach is checked on the host
+    bad = idx.clone()
+    bad[5] = B
+    bad[N - 3] = -1
+    bad[7001] = 1 << 30
+    d_st2 = torch.empty(N, dtype=torch.uint8, device="cuda")
+    nxt2 = torch.empty((N, 2), dtype=torch.float32, device="cuda")
+    err2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), bad.data_ptr(), B, nxt2.data_ptr(),
+                                  d_st2.data_ptr(), err2.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0))
+    st2 = d_st2.cpu().numpy()
+    keep = np.ones(N, bool)
+    keep[[5, N - 3, 7001]] = False
+    assert not st2[~keep].any() and np.array_equal(st2[keep], st[keep]) and np.array_equal(nxt2.cpu().numpy()[keep], nxt[keep])
+    assert (err2.cpu().numpy()[~keep] == 0).all()
+    assert fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, allp.data_ptr(), idx.data_ptr(), B + 1, nxt2.data_ptr(),
+                              d_st2.data_ptr(), err2.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0) == -1
+    assert fe.L.vofe_track_fb(fe.ctx, pyr._h, B + 1, pyr._h, 0, allp.data_ptr(), idx.data_ptr(), B, nxt2.data_ptr(),
+                              d_st2.data_ptr(), err2.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0) == -1
+    pyr.free()
+
+
+def test_config3_64_kitti_sequences_full_shape(fe):
+    """BASELINE.json configs[3] as SURVEY 8d defines it, at full shape: 64 independent KITTI-shaped 1241x376 sequences
+    (seeds 100 + s), K = 1000 landmarks + M = 1000 candidates per sequence, advanced over 3 frame steps by ONE pyramid
+    build + ONE tracker launch per frame index (MultiSequenceTracker) plus batched detection -- every sequence, every
+    frame, both point sets and the corner lists against the oracle, bit for bit."""
+    from visual_odometry_amd import MultiSequenceTracker
+    H, W, _, _, win, lvl = synthetic.CONFIGS["kitti"]
+    B, K, M, F = 64, 1000, 1000, 4
+    seqs = [synthetic.sequence(H, W, seed=100 + s, n_frames=F) for s in range(B)]
+    multi = MultiSequenceTracker(B, H, W, winSize=win, maxLevel=lvl, frontend=fe)
+    multi.reset(np.stack([q[0] for q in seqs]))
+    det = multi.detect(K + M, 0.01, 7)
+    land, cand = [], []
+    for s in range(B):
+        ref = oracle.goodFeaturesToTrack(seqs[s][0], K + M, 0.01, 7, nthreads=16)
+        assert np.array_equal(det[s], ref), s
+        p = synthetic.pad_points(ref, K + M, H, W, 100 + s)
+        land.append(p[0::2].T.copy())            # strongest corners alternate between the two sets
+        cand.append(p[1::2].T.copy())
+    total = 0
+    for f in range(1, F):
+        sets = [np.concatenate([land[s], cand[s]], axis=1) for s in range(B)]
+        got = multi.track(np.stack([q[f] for q in seqs]), sets)
+        corners = multi.detect(1000, 0.01, 10)                        # the reference's per-frame detection (constants.py:31-33)
+        for s in range(B):
+            kl = land[s].shape[1]
+            gt, gs, ge = got[s]
+            for name, pts, sl in (("landmarks", land[s], slice(0, kl)), ("candidates", cand[s], slice(kl, None))):
+                rt, rs, re = oracle.track_keypoints(pts, seqs[s][f - 1], seqs[s][f], win, lvl, (3, 30, 0.01), 1e-3, 1.0, nthreads=16)
+                assert np.array_equal(gs[sl], rs) and np.array_equal(gt[:, sl], rt) and np.array_equal(ge[sl], re), (f, s, name)
+            assert np.array_equal(corners[s], oracle.goodFeaturesToTrack(seqs[s][f], 1000, 0.01, 10, nthreads=16)), (f, s)
+            # carry the survivors, as process_frame does (continuous.py:90-92, 391-396)
+            land[s] = gt[:, :kl][:, gs[:kl] == 1]
+            cand[s] = gt[:, kl:][:, gs[kl:] == 1]
+            total += land[s].shape[1] + cand[s].shape[1]
+    assert total > 0.8 * B * (K + M) * (F - 1)
+    multi.close()
+
+
+def test_gftt_host_capacity_below_the_corner_count(fe):
+    """vofe_gftt_host delivers min(count, capacity) corners to the host buffer and never writes past it: capacity below
+    maxCorners, and maxCorners = 0 with a small capacity (guard region behind the buffer)."""
+    import ctypes as C
+    import torch
+    a = _seq(240, 320, 12, 1)[0]
+    d = torch.from_numpy(a).cuda()
+    for maxc, cap in ((300, 40), (0, 25), (300, 1), (50, 400)):
+        ref = oracle.goodFeaturesToTrack(a, maxc, 0.01, 6).reshape(-1, 2)
+        host = np.full((cap + 64, 2), -3.0, np.float32)
+        dev = torch.full((cap, 2), -3.0, dtype=torch.float32, device="cuda")
+        n = C.c_int(-1)
+        rc = fe.L.vofe_gftt_host(fe.ctx, d.data_ptr(), 240, 320, 320, maxc, 0.01, 6.0, None, 3, 3, 0, 0.04, dev.data_ptr(),
+                                 host.ctypes.data, cap, C.byref(n))
+        assert rc == 0 and n.value == ref.shape[0], (maxc, cap, n.value)
+        m = min(cap, ref.shape[0])
+        assert np.array_equal(host[:m], ref[:m]) and (host[m:] == -3.0).all(), (maxc, cap)
+        assert np.array_equal(dev.cpu().numpy()[:m], ref[:m])
 
 
 # ------------------------------------------------------------------ candidate bookkeeping (SURVEY 8f rank 2)
@@ -880,7 +1001,7 @@ def test_randomised_lk_sweep_all_window_shapes(fe):
     assert len(seen_r) >= 12
 
 
-def test_randomised_lk_21x21_sweep_all_kernels(fe, monkeypatch):
+def test_randomised_lk_21x21_sweep_all_kernels(fe, knob):
     """Random frames, point sets (interior, border, far outside, NaN), criteria and flags through the three 21x21
     kernels (one, two and four keypoints per wavefront) and the tracker glue: identical to the oracle, bit for bit."""
     import os
@@ -903,14 +1024,14 @@ def test_randomised_lk_21x21_sweep_all_kernels(fe, monkeypatch):
             n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig, nthreads=8)
             t0 = oracle.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig, 1.0, 8)
         for kern in ("x1", "x2", "x4"):
-            monkeypatch.setenv("VOFE_LK", kern)
+            knob("VOFE_LK", kern)
             n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig)
             assert np.array_equal(s0, s1), (case, kern, h, w, lvl)
             assert np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True), (case, kern, h, w, lvl)
             t1 = fe.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig)
             for x, y in zip(t0, t1):
                 assert np.array_equal(x, y, equal_nan=True), (case, kern, "fb")
-        monkeypatch.delenv("VOFE_LK")
+        knob("VOFE_LK")
 
 
 def test_randomised_gftt_sweep(fe):
@@ -936,7 +1057,7 @@ def test_randomised_gftt_sweep(fe):
             assert np.array_equal(got, ref), (case, h, w, q, md, maxc, harris)
 
 
-def test_randomised_score_sweep(fe, monkeypatch):
+def test_randomised_score_sweep(fe, knob):
     """Score maps of random frames, bit for bit: sizes around the strip kernel's internal boundaries (4-column
     threads, 256-column waves, strip heights), every strip height forced in turn, smooth / noisy / posterised /
     saturated content, Shi-Tomasi and Harris."""
@@ -957,8 +1078,8 @@ def test_randomised_score_sweep(fe, monkeypatch):
             a[: h // 2] = 255                                          # large flat part: zero scores, zero sqrt arguments
         rs = ("2", "4", "8", "16", None)[case % 5]
         if rs is None:
-            monkeypatch.delenv("VOFE_SCORE_RS", raising=False)
+            knob("VOFE_SCORE_RS")
         else:
-            monkeypatch.setenv("VOFE_SCORE_RS", rs)
+            knob("VOFE_SCORE_RS", rs)
         harris = bool(case % 3 == 0)
         assert np.array_equal(fe.corner_score(a, harris, 0.04), oracle.corner_score(a, harris, 0.04)), (case, h, w, kind, rs, harris)

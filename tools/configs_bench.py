@@ -45,7 +45,7 @@ def front_end_frame(fe, cfg, md, reps):
     pyr = Pyramid(fe, 2, H, W, win, lvl, True)
 
     def track(slot_a, slot_b):
-        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, slot_a, pyr._h, slot_b, dp.data_ptr(), None, dn.data_ptr(), ds.data_ptr(),
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, slot_a, pyr._h, slot_b, dp.data_ptr(), None, 1, dn.data_ptr(), ds.data_ptr(),
                                    de.data_ptr(), n, 3, 30, 0.01, 1e-3, 1.0))
 
     def ref_equiv():
@@ -105,7 +105,7 @@ def sequences_64(fe, reps):
 
     def step():
         _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2 * B, d.data_ptr(), W, H * W))
-        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, dp.data_ptr(), idx.data_ptr(), dn.data_ptr(), ds.data_ptr(),
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, dp.data_ptr(), idx.data_ptr(), B, dn.data_ptr(), ds.data_ptr(),
                                    de.data_ptr(), N, 3, 30, 0.01, 1e-3, 1.0))
     t = timed(step, reps)
     out, cnt = None, None

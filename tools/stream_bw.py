@@ -1,7 +1,7 @@
 """Streaming kernels on large launches (roofline fractions are quoted on the stress frame and on
 batched launches): builds pyramids of 128 KITTI frames and of 2 4K frames with the per-level kernels and
-the score map of the same inputs.  Run under `rocprofv3 --kernel-trace`; scratch/stream_bw_sum.py turns the
-trace into GB/s per kernel with the algorithmic bytes of SURVEY 8d."""
+the score map of the same inputs.  Run under `rocprofv3 --kernel-trace`; bench.py's roofline_streaming block reports the same
+kernels in GB/s with the algorithmic bytes of SURVEY 8d."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 os.environ["VOFE_PYRAMID"] = "levels"

@@ -8,10 +8,10 @@ LIB_PATH = os.environ.get("VOFE_LIB", os.path.join(_HERE, "libvofe.so"))
 
 # every symbol include/vofe.h declares (tests check the built library exports all of them)
 SYMBOLS = (
-    "vofe_last_error", "vofe_version", "vofe_create", "vofe_destroy", "vofe_synchronize",
+    "vofe_last_error", "vofe_version", "vofe_create", "vofe_destroy", "vofe_synchronize", "vofe_reload_env",
     "vofe_pyramid_create", "vofe_pyramid_free", "vofe_pyramid_build", "vofe_pyramid_levels",
     "vofe_pyramid_level_size", "vofe_pyramid_download", "vofe_pyramid_download_padded",
-    "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_corner_score", "vofe_gftt", "vofe_gftt_host", "vofe_gftt_batch", "vofe_new_feature_mask",
+    "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_profile_begin", "vofe_profile_end", "vofe_corner_score", "vofe_gftt", "vofe_gftt_host", "vofe_gftt_batch", "vofe_new_feature_mask",
     "vofe_candidate_filter", "vofe_triangulate_candidates",
 )
 
@@ -43,6 +43,7 @@ def load():
     L.vofe_create.argtypes = [i, vp, C.POINTER(vp)]
     L.vofe_destroy.argtypes = [vp]
     L.vofe_synchronize.argtypes = [vp]
+    L.vofe_reload_env.argtypes = [vp]
     L.vofe_pyramid_create.argtypes = [vp, i, i, i, i, i, i, i, C.POINTER(vp)]
     L.vofe_pyramid_free.argtypes = [vp, vp]
     L.vofe_pyramid_build.argtypes = [vp, vp, i, i, vp, i, sz]
@@ -50,9 +51,11 @@ def load():
     L.vofe_pyramid_level_size.argtypes = [vp, i, ip, ip]
     L.vofe_pyramid_download.argtypes = [vp, vp, i, i, vp, vp]
     L.vofe_pyramid_download_padded.argtypes = [vp, vp, i, i, i, i, vp]
-    L.vofe_lk_track.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, i, d]
-    L.vofe_track_fb.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, vp, i, i, i, d, d, f]
+    L.vofe_lk_track.argtypes = [vp, vp, i, vp, i, vp, vp, i, vp, vp, vp, i, i, i, d, i, d]
+    L.vofe_track_fb.argtypes = [vp, vp, i, vp, i, vp, vp, i, vp, vp, vp, i, i, i, d, d, f]
     L.vofe_lk_set_counters.argtypes = [vp, vp]
+    L.vofe_profile_begin.argtypes = [vp]
+    L.vofe_profile_end.argtypes = [vp, i, vp, vp, ip]
     L.vofe_corner_score.argtypes = [vp, vp, i, i, i, i, sz, i, i, i, d, vp]
     L.vofe_gftt.argtypes = [vp, vp, i, i, i, i, d, d, vp, i, i, i, d, vp, i, ip]
     L.vofe_gftt_host.argtypes = [vp, vp, i, i, i, i, d, d, vp, i, i, i, d, vp, vp, i, ip]

@@ -2,6 +2,7 @@
 // context / pyramid object management, and dispatch to the kernel launchers.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,6 +20,32 @@ void vofe_set_error(const char* fmt, ...) {
 int vofe_hip_fail(hipError_t e, const char* what) {
     vofe_set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
     return VOFE_E_HIP;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+static bool env_is(const char* name, char first) {
+    const char* v = getenv(name);
+    return v && v[0] == first;
+}
+void vofe_read_knobs(VofeKnobs* k) {
+    memset(k, 0, sizeof(*k));
+    if (const char* v = getenv("VOFE_LK")) { strncpy(k->lk, v, sizeof(k->lk) - 1); }
+    if (const char* v = getenv("VOFE_PYRAMID")) k->pyramid = (v[0] == 'f' || v[0] == 'l') ? v[0] : 0;
+    k->pad_copy_generic = env_is("VOFE_PAD_COPY", 'g');
+    k->score_tile = env_is("VOFE_CORNER_SCORE", 't');
+    k->score_rs = env_int("VOFE_SCORE_RS", 0);
+    k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
+    k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
+    k->gftt_chain = env_is("VOFE_GFTT_CHAIN", 's');
+    k->sel_blocks = env_int("VOFE_SEL_BLOCKS", 1024);
+    k->sel_launches = env_int("VOFE_SEL_LAUNCHES", 1);
+    k->sel_passes = env_int("VOFE_SEL_PASSES", 2);
+    k->sel_spins = env_int("VOFE_SEL_SPINS", 64);
+    k->sel_prefix = env_int("VOFE_SEL_PREFIX", 0);
+    k->sel_full = env_int("VOFE_SEL_FULL", 0);
 }
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -64,7 +91,15 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
     c->h_pinned = nullptr; c->d_pinned = nullptr; c->h_pinned_ints = 0;
     c->gftt_clean_batch = 0; c->gftt_clean_ws = nullptr;
     c->lk_counters = nullptr;
+    c->prof = nullptr;
+    vofe_read_knobs(&c->knobs);
     *out = c;
+    return VOFE_OK;
+}
+
+int vofe_reload_env(vofe_ctx* ctx) {
+    if (!ctx) { vofe_set_error("vofe_reload_env: ctx is NULL"); return VOFE_E_ARG; }
+    vofe_read_knobs(&ctx->knobs);
     return VOFE_OK;
 }
 
@@ -74,6 +109,10 @@ int vofe_destroy(vofe_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->prof) {
+        for (auto& e : ctx->prof->entries) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        delete ctx->prof;
+    }
     delete ctx;
     return VOFE_OK;
 }
@@ -123,11 +162,14 @@ int vofe_pyramid_create(vofe_ctx* ctx, int slots, int height, int width, int win
     p->levels = n;
     hipError_t e = hipMalloc((void**)&p->d_I, (size_t)total + 256);
     if (e != hipSuccess) { delete p; return vofe_hip_fail(e, "hipMalloc(pyramid images)"); }
-    hipMemsetAsync(p->d_I, 0, (size_t)total + 256, ctx->stream);
+    e = hipMemsetAsync(p->d_I, 0, (size_t)total + 256, ctx->stream);
+    if (e != hipSuccess) { hipFree(p->d_I); delete p; return vofe_hip_fail(e, "hipMemsetAsync(pyramid images)"); }
     if (p->with_deriv) {
         e = hipMalloc((void**)&p->d_D, ((size_t)total + 64) * 4);
         if (e != hipSuccess) { hipFree(p->d_I); delete p; return vofe_hip_fail(e, "hipMalloc(pyramid derivatives)"); }
-        hipMemsetAsync(p->d_D, 0, ((size_t)total + 64) * 4, ctx->stream);
+        // the zero border of the derivative planes (cv: BORDER_CONSTANT) is never written by a kernel: it must be cleared
+        e = hipMemsetAsync(p->d_D, 0, ((size_t)total + 64) * 4, ctx->stream);
+        if (e != hipSuccess) { hipFree(p->d_I); hipFree(p->d_D); delete p; return vofe_hip_fail(e, "hipMemsetAsync(pyramid derivatives)"); }
     }
     for (int l = 0; l < n; ++l) {
         VofeLevel& L = p->lv[l];
@@ -214,8 +256,8 @@ int vofe_pyramid_download(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, int leve
 
 // ------------------------------------------------------------------------------- LK
 static int lk_common(const char* who, vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                     int next_slot, const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
-                     int n, int need_next_deriv) {
+                     int next_slot, const float* d_prev_pts, const int* d_img_idx, int& n_images, float* d_next_pts,
+                     uint8_t* d_status, float* d_err, int n, int need_next_deriv) {
     if (!ctx || !prev || !next) { vofe_set_error("%s: NULL ctx or pyramid", who); return VOFE_E_ARG; }
     if (n < 0) { vofe_set_error("%s: n < 0", who); return VOFE_E_ARG; }
     if (n > 0 && (!d_prev_pts || !d_next_pts || !d_status || !d_err)) { vofe_set_error("%s: NULL point buffer", who); return VOFE_E_ARG; }
@@ -228,8 +270,13 @@ static int lk_common(const char* who, vofe_ctx* ctx, const vofe_pyr* prev, int p
         vofe_set_error("%s: pyramid built without derivative planes", who);
         return VOFE_E_ARG;
     }
-    if (prev_slot < 0 || prev_slot >= prev->slots || next_slot < 0 || next_slot >= next->slots) {
-        vofe_set_error("%s: slot out of range", who);
+    if (!d_img_idx) n_images = 1;
+    if (n_images < 1) { vofe_set_error("%s: n_images must be >= 1 with an image index", who); return VOFE_E_ARG; }
+    // the kernels address slot + img_idx[i]: the whole index range must lie inside both pyramid objects
+    if (prev_slot < 0 || next_slot < 0 || (long long)prev_slot + n_images > prev->slots ||
+        (long long)next_slot + n_images > next->slots) {
+        vofe_set_error("%s: slots [%d,+%d) / [%d,+%d) outside the pyramids (%d / %d slots)", who, prev_slot, n_images,
+                       next_slot, n_images, prev->slots, next->slots);
         return VOFE_E_ARG;
     }
     return VOFE_OK;
@@ -241,27 +288,59 @@ static void lk_criteria(int type, int& max_count, double& eps) {        // SURVE
 }
 
 int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
                   int flags, double min_eig_thr) {
-    int rc = lk_common("vofe_lk_track", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 0);
+    int rc = lk_common("vofe_lk_track", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts,
+                       d_status, d_err, n, 0);
     if (rc || n == 0) return rc;
     VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
-    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
+    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err, n,
                           max_count, eps, flags, (float)min_eig_thr, 0, 0.f);
 }
 
 int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                  int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                  int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,
                   double min_eig_thr, float fb_thresh) {
-    int rc = lk_common("vofe_track_fb", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, 1);
+    int rc = lk_common("vofe_track_fb", ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts,
+                       d_status, d_err, n, 1);
     if (rc || n == 0) return rc;
     VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
-    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, d_next_pts, d_status, d_err, n,
+    return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err, n,
                           max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
+}
+
+int vofe_profile_begin(vofe_ctx* ctx) {
+    if (!ctx) { vofe_set_error("vofe_profile_begin: ctx is NULL"); return VOFE_E_ARG; }
+    if (!ctx->prof) ctx->prof = new (std::nothrow) VofeProf();
+    if (!ctx->prof) { vofe_set_error("vofe_profile_begin: out of host memory"); return VOFE_E_NOMEM; }
+    return VOFE_OK;
+}
+
+int vofe_profile_end(vofe_ctx* ctx, int capacity, char* names, float* ms, int* n_out) {
+    if (!ctx || !n_out || capacity < 0 || (capacity > 0 && (!names || !ms))) { vofe_set_error("vofe_profile_end: bad argument"); return VOFE_E_ARG; }
+    *n_out = 0;
+    if (!ctx->prof) return VOFE_OK;
+    VOFE_BIND(ctx);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    int n = 0;
+    for (auto& en : ctx->prof->entries) {
+        float t = 0.f;
+        if (e == hipSuccess && n < capacity && hipEventElapsedTime(&t, en.a, en.b) == hipSuccess) {
+            strncpy(names + (size_t)n * VOFE_PROFILE_NAME_LEN, en.name.c_str(), VOFE_PROFILE_NAME_LEN - 1);
+            names[(size_t)n * VOFE_PROFILE_NAME_LEN + VOFE_PROFILE_NAME_LEN - 1] = 0;
+            ms[n++] = t;
+        }
+        hipEventDestroy(en.a); hipEventDestroy(en.b);
+    }
+    delete ctx->prof;
+    ctx->prof = nullptr;
+    *n_out = n;
+    if (e != hipSuccess) return vofe_hip_fail(e, "hipStreamSynchronize");
+    return VOFE_OK;
 }
 
 int vofe_lk_set_counters(vofe_ctx* ctx, unsigned long long* d_counters) {

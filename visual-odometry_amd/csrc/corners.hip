@@ -799,11 +799,6 @@ __global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __r
     }
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 int ensure_ws(vofe_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return VOFE_OK;
     if (ctx->ws) { hipStreamSynchronize(ctx->stream); hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
@@ -831,37 +826,41 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
                              size_t img_stride, int harris, float k, float* d_score,
                              unsigned* d_hdr, const uint8_t* d_mask) {
     if (batch > 65535) { vofe_set_error("corner_score: batch too large"); return VOFE_E_UNSUPPORTED; }
-    const char* force = getenv("VOFE_CORNER_SCORE");             // "tile" forces the LDS-tile kernel (tests)
-    if (w >= 8 && h >= 4 && !(force && force[0] == 't')) {
+    if (w >= 8 && h >= 4 && !ctx->knobs.score_tile) {            // VOFE_CORNER_SCORE=tile forces the LDS-tile kernel (tests)
         // strips of 8 rows; 4 rows while that leaves SIMDs without a wave (small frames are latency bound)
         long long waves8 = (long long)((w + 255) / 256) * ((h + 7) / 8) * batch;
-        if (const char* rs = getenv("VOFE_SCORE_RS"))            // 2, 4, 8 or 16 rows per strip (tests, tuning)
-            waves8 = atoi(rs) >= 16 ? 3072 : atoi(rs) >= 8 ? 1024 : atoi(rs) >= 4 ? 512 : 0;
+        if (const int rs = ctx->knobs.score_rs)                  // VOFE_SCORE_RS: 2, 4, 8 or 16 rows per strip (tests, tuning)
+            waves8 = rs >= 16 ? 3072 : rs >= 8 ? 1024 : rs >= 4 ? 512 : 0;
         if (waves8 >= 3072) {
             // more 8-row waves than the chip holds at once (3 per SIMD at this register count): 16-row strips
             // halve the wave count and trim the 4 halo rows per strip
             dim3 grid((w + 255) / 256, (h + 63) / 64, batch);
             if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+            VOFE_TIMED(ctx, "corner_score_strip<16>");
             hipLaunchKernelGGL(corner_score_strip<16>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
         } else if (waves8 >= 1024) {
             dim3 grid((w + 255) / 256, (h + 31) / 32, batch);
             if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+            VOFE_TIMED(ctx, "corner_score_strip<8>");
             hipLaunchKernelGGL(corner_score_strip<8>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
         } else if (waves8 >= 512) {
             dim3 grid((w + 255) / 256, (h + 15) / 16, batch);
+            VOFE_TIMED(ctx, "corner_score_strip<4>");
             hipLaunchKernelGGL(corner_score_strip<4>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
         } else {
             // a single small frame: 2-row strips double the wave count again (the kernel is pure latency there)
             dim3 grid((w + 255) / 256, (h + 7) / 8, batch);
+            VOFE_TIMED(ctx, "corner_score_strip<2>");
             hipLaunchKernelGGL(corner_score_strip<2>, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                                d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
         }
     } else {
         dim3 grid((w + TX - 1) / TX, (h + TY - 1) / TY, batch);
         if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+        VOFE_TIMED(ctx, "corner_score_f32");
         hipLaunchKernelGGL(corner_score_f32, grid, dim3(256), 0, ctx->stream, d_img, h, w, pitch, img_stride, harris, k,
                            d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
     }
@@ -909,12 +908,13 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const bool suppress = min_distance >= 1.0;
     // schedule of the selection (measured, profiles/r01_host_paths.txt; any values give the same corners, see
     // tools/knob_matrix.sh): one launch of 4096 waves, two sweeps, a blocked candidate polls its blockers up to 64 times
-    static const int sel_blocks = std::max(env_int("VOFE_SEL_BLOCKS", 1024), 1);
-    static const int sel_launches = std::min(std::max(env_int("VOFE_SEL_LAUNCHES", 1), 1), SELECT_ROUNDS);
-    static const int sel_passes = std::max(env_int("VOFE_SEL_PASSES", 2), 1);
-    static const int sel_spins = std::max(env_int("VOFE_SEL_SPINS", 64), 0);
-    static const int sel_prefix_env = env_int("VOFE_SEL_PREFIX", 0);       // > 0: fixed first-prefix factor (tests, tuning)
-    static const int sel_full_env = env_int("VOFE_SEL_FULL", 0);           // > 0: fixed whole-list ratio
+    const VofeKnobs& kn = ctx->knobs;
+    const int sel_blocks = std::max(kn.sel_blocks, 1);
+    const int sel_launches = std::min(std::max(kn.sel_launches, 1), SELECT_ROUNDS);
+    const int sel_passes = std::max(kn.sel_passes, 1);
+    const int sel_spins = std::max(kn.sel_spins, 0);
+    const int sel_prefix_env = kn.sel_prefix;                              // > 0: fixed first-prefix factor (tests, tuning)
+    const int sel_full_env = kn.sel_full;                                  // > 0: fixed whole-list ratio
     // How many of the best-ranked candidates hold maxCorners accepted ones?  On densely textured frames the accepted
     // corners saturate at about one per 1.7 * minDistance^2 pixels (capacity C; measured 5366 on 1241x376 at 7 px, 2868
     // on 800x600 at 10 px, 1849 on 640x480 at 10 px) and the best K candidates hold about C * (1 - exp(-K / 1.5 C)) of
@@ -947,11 +947,14 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
+    { VOFE_TIMED(ctx, "nms_map");
     hipLaunchKernelGGL(nms_map, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
-                       score, h, w, quality, hdr, state, ckey, hist, d_mask);
-    hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full);
+                       score, h, w, quality, hdr, state, ckey, hist, d_mask); }
+    { VOFE_TIMED(ctx, "bucket_scan");
+    hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full); }
+    { VOFE_TIMED(ctx, "bucket_scatter");
     hipLaunchKernelGGL(bucket_scatter, dim3((unsigned)std::min<size_t>((px + 2047) / 2048, 2048), batch), dim3(256), 0, st,
-                       state, h, w, cursor, cand);
+                       state, h, w, cursor, cand); }
     int r = 0;
     float md2 = 0.f;
     if (suppress) {
@@ -965,8 +968,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     unsigned* rank = reinterpret_cast<unsigned*>(score);         // the score map is dead after nms_compact
     int max_out = capacity;
     if (max_corners > 0 && max_corners < max_out) max_out = max_corners;
-    const char* force = getenv("VOFE_GFTT_SORT");                 // "bitonic" forces the network (tests)
-    const bool use_rank = !(force && force[0] == 'b');
+    const bool use_rank = !kn.gftt_bitonic;                       // VOFE_GFTT_SORT=bitonic forces the network (tests)
     int seg = 0;
     for (int pass = 0;; ++pass) {
         if (pass > 0) {
@@ -977,18 +979,23 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             }
         }
         if (suppress)
-            for (int round = 0; round < sel_launches; ++round)
+            for (int round = 0; round < sel_launches; ++round) {
+                VOFE_TIMED(ctx, "select_round");
                 hipLaunchKernelGGL(select_round, dim3(sel_blocks, batch), dim3(256), 0, st, ckey, h, w, r, md2, hdr, state,
                                    cand, seg, sel_passes, sel_spins, round);
+            }
+        { VOFE_TIMED(ctx, "gather_accepted");
         hipLaunchKernelGGL(gather_accepted, dim3(256, batch), dim3(256), 0, st, ckey, h, w, hdr, state, cand, keys,
-                           rank, suppress ? 0 : 1, seg);
+                           rank, suppress ? 0 : 1, seg); }
         if (use_rank && max_out > 0) {
             // the sort runs speculatively behind the gather (sized by the device-side count), so the
             // common case needs one host round trip per call
             unsigned long long ub = seg_base ? ((unsigned long long)seg_base << seg) : px;
             ub = std::min<unsigned long long>(std::min<unsigned long long>(ub + ub / 4, px), RANK_MAX);
             const unsigned gi = (unsigned)((ub + 255) / 256), gj = (unsigned)((ub + RANK_J - 1) / RANK_J);
-            hipLaunchKernelGGL(rank_count, dim3(gi, gj, batch), dim3(256), 0, st, keys, hdr, px, rank, px);
+            { VOFE_TIMED(ctx, "rank_count");
+            hipLaunchKernelGGL(rank_count, dim3(gi, gj, batch), dim3(256), 0, st, keys, hdr, px, rank, px); }
+            VOFE_TIMED(ctx, "emit_ranked");
             // the emit kernel delivers header and (single image) corner list straight into pinned host memory
             hipLaunchKernelGGL(emit_ranked, dim3(gi, batch), dim3(256), 0, st, keys, hdr, px, rank, px, w, d_corners_xy,
                                capacity, max_out, reinterpret_cast<GfttHdr*>(ctx->d_pinned),
@@ -1002,7 +1009,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             if (suppress && hh[b].undecided[sel_launches - 1]) converged = false;
             if (hh[b].seg_end[seg] < hh[b].n_cand && (max_corners <= 0 || hh[b].n_acc < (unsigned)max_corners)) enough = false;
         }
-        if (getenv("VOFE_GFTT_DEBUG"))
+        if (kn.gftt_debug)
             fprintf(stderr, "gftt pass %d seg %d: n_cand %u seg_end %u n_acc %u undecided %u converged %d enough %d\n", pass, seg,
                     hh[0].n_cand, hh[0].seg_end[seg], hh[0].n_acc, hh[0].undecided[sel_launches - 1], (int)converged, (int)enough);
         if (converged && enough) break;
@@ -1036,7 +1043,8 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     if (use_rank && nmax <= RANK_MAX) {
         // already sorted and emitted by the speculative rank sort
         if (h_corners_xy && stage_floats) {
-            memcpy(h_corners_xy, reinterpret_cast<int*>(ctx->h_pinned) + hdr_ints, (size_t)h_n_out[0] * 2 * sizeof(float));
+            memcpy(h_corners_xy, reinterpret_cast<int*>(ctx->h_pinned) + hdr_ints,
+                   (size_t)std::min(h_n_out[0], max_out) * 2 * sizeof(float));     // only min(count, capacity) pairs were staged
             return VOFE_OK;
         }
     } else if (chunks == 1) {

@@ -32,6 +32,7 @@ struct LKArgs {
     int slot_a, slot_b;
     const float2* prev_pts;
     const int* img_idx;
+    int n_images;              // valid image indices are [0, n_images); anything else loses the point (status 0)
     float2* next_pts;
     uint8_t* status;
     float* err;
@@ -433,13 +434,15 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     const int ny = REG ? (active ? R : 0) : (active ? min(rpg, wh - y0) : 0);
 
     const float2 p = a.prev_pts[i];
-    const int idx = a.img_idx ? a.img_idx[i] : 0;
+    int idx = a.img_idx ? a.img_idx[i] : 0;
+    const bool bad_idx = (unsigned)idx >= (unsigned)a.n_images;      // wave-uniform: never address a slot outside the batch
+    if (bad_idx) idx = 0;
     float fx = 0.f, fy = 0.f;
     if (a.flags & 4) { const float2 q = a.next_pts[i]; fx = q.x; fy = q.y; }
-    int st = 1;
+    int st = bad_idx ? 0 : 1;
     float er = 0.f;
     float bx = 0.f, by = 0.f;
-    const int ndir = a.fb ? 2 : 1;
+    const int ndir = bad_idx ? 0 : (a.fb ? 2 : 1);
     unsigned n_lv = 0, n_it = 0;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int dir = 0; dir < ndir; ++dir) {      // dir 1 = backward pass from the forward result
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
         if (dx != dx || dy != dy) d = __builtin_nanf("");
         st = st & (d < a.fb_thresh ? 1 : 0);
     }
+    if (bad_idx) { st = 0; er = 0.f; }
     if (lane == 0) {
         a.next_pts[i] = make_float2(fx, fy);
         a.status[i] = (uint8_t)st;
@@ -767,7 +771,9 @@ __global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
         sy0[s] = g * x2::R;
     }
     const float2 p = a.prev_pts[i];
-    const int idx = a.img_idx ? a.img_idx[i] : 0;
+    int idx = a.img_idx ? a.img_idx[i] : 0;
+    const bool bad_idx = (unsigned)idx >= (unsigned)a.n_images;      // group-uniform: tracked in slot 0, reported lost
+    if (bad_idx) idx = 0;
     float fx = 0.f, fy = 0.f;
     if (a.flags & 4) { const float2 q = a.next_pts[i]; fx = q.x; fy = q.y; }
     int st = 1;
@@ -794,6 +800,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
         if (dx != dx || dy != dy) d = __builtin_nanf("");
         st = st & (d < a.fb_thresh ? 1 : 0);
     }
+    if (bad_idx) { st = 0; er = 0.f; }
     if (l32 == 0 && valid) {
         a.next_pts[i] = make_float2(fx, fy);
         a.status[i] = (uint8_t)st;
@@ -814,7 +821,7 @@ void launch_r(const LKArgs& a, size_t lds_bytes, hipStream_t st) {
 }  // namespace
 
 int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                   int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                   int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                    uint8_t* d_status, float* d_err, int n, int max_count, double eps2, int flags,
                    float min_eig_thr, int fb, float fb_thresh) {
     LKArgs a;
@@ -823,6 +830,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     a.slot_a = prev_slot; a.slot_b = next_slot;
     a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
     a.img_idx = d_img_idx;
+    a.n_images = d_img_idx ? n_images : 1;
     a.next_pts = reinterpret_cast<float2*>(d_next_pts);
     a.status = d_status; a.err = d_err; a.n = n;
     a.win_w = prev->win_w; a.win_h = prev->win_h;
@@ -849,7 +857,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     const size_t lds_bytes = (size_t)a.rs * a.rh * 4;
     const int R = a.rows_per_group;
     hipStream_t st = ctx->stream;
-    const char* force = getenv("VOFE_LK");                       // "generic" skips the 21x21 specialisation (tests)
+    const char* force = ctx->knobs.lk[0] ? ctx->knobs.lk : nullptr;   // VOFE_LK: "generic" skips the 21x21 specialisation (tests)
     // large 21x21 launches saturate the vector ALUs: two keypoints per wavefront share the uniform work there;
     // small launches are latency bound and keep one keypoint per wavefront ("x2" / "x1" force a kernel)
     // (its 32-bit lane offsets must span every slot of a level's derivative plane)

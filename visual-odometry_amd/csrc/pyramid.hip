@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void pyramid_borders_wide(const VofeLevel* __r
 }
 
 // Launches the border kernel for levels first_level.. (the wide one when every such level is wide enough).
-void launch_borders(const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st);
+void launch_borders(const vofe_ctx* ctx, const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st);
 
 BorderPlan border_plan(const vofe_pyr* pyr, int first_level, int* total_blocks) {
     BorderPlan plan;
@@ -461,10 +461,9 @@ BorderPlan border_plan(const vofe_pyr* pyr, int first_level, int* total_blocks) 
 
 inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }   // floor division
 
-void launch_borders(const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st) {
+void launch_borders(const vofe_ctx* ctx, const vofe_pyr* pyr, int first_level, int slot0, int count, hipStream_t st) {
     const int ww = pyr->win_w, wh = pyr->win_h, nl = (ww + 15) / 16;
-    const char* pc = getenv("VOFE_PAD_COPY");                       // "generic" forces the any-width kernels (tests)
-    bool wide = !(pc && pc[0] == 'g');
+    bool wide = !ctx->knobs.pad_copy_generic;                       // VOFE_PAD_COPY=generic forces the any-width kernels (tests)
     for (int l = first_level; l < pyr->levels; ++l) wide = wide && pyr->lv[l].w >= 16 * nl + 17;
     int total = 0;
     if (wide) {
@@ -477,9 +476,11 @@ void launch_borders(const vofe_pyr* pyr, int first_level, int slot0, int count, 
             total += (int)((2ll * wh * ng + 2ll * nl * pyr->lv[l].h + 255) / 256);
         }
         plan.blk_start[pyr->levels] = total;
+        VOFE_TIMED(const_cast<vofe_ctx*>(ctx), "pyramid_borders_wide");
         if (total > 0) hipLaunchKernelGGL(pyramid_borders_wide, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
     } else {
         const BorderPlan plan = border_plan(pyr, first_level, &total);
+        VOFE_TIMED(const_cast<vofe_ctx*>(ctx), "pyramid_borders");
         if (total > 0) hipLaunchKernelGGL(pyramid_borders, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0, ww, wh);
     }
 }
@@ -493,9 +494,9 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     // Small frames are launch/latency bound: one fused launch for all levels wins (KITTI pair 21.6 vs 30 us).
     // Large frames are bandwidth bound and the halo recompute of the fused kernel costs more than the extra
     // launches (3840x2160 pair: 134 us fused vs 77 us per-level), so they take the per-level kernels.
-    const char* force = getenv("VOFE_PYRAMID");          // "fused" / "levels" force one path (tests, measurements)
-    const bool small = (long long)pyr->height * pyr->width * count <= 2000000ll;      // measured cross-over (scratch/pyr_switch.py)
-    const bool fused = force ? force[0] == 'f' : small;
+    const char force = ctx->knobs.pyramid;               // VOFE_PYRAMID: "fused" / "levels" force one path (tests, measurements)
+    const bool small = (long long)pyr->height * pyr->width * count <= 2000000ll;      // measured cross-over
+    const bool fused = force ? force == 'f' : small;
     if (pyr->levels <= FUSE_MAX_LEVELS && fused) {
         // fused path: 2 launches (interiors + Scharr, then border bands)
         FusePlan P;
@@ -512,9 +513,12 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         const VofeLevel& Lt = pyr->lv[T];
         dim3 grid((Lt.w + P.tw - 1) / P.tw, (Lt.h + P.th - 1) / P.th, count);
         if (grid.y > 65535) { vofe_set_error("pyramid: image too tall"); return VOFE_E_UNSUPPORTED; }
+        {
+        VOFE_TIMED(ctx, "pyramid_fused");
         hipLaunchKernelGGL(pyramid_fused, grid, dim3(1024), (size_t)off, st, d_img, pitch, img_stride, pyr->d_lv, P, slot0,
                            pyr->with_deriv);
-        launch_borders(pyr, 0, slot0, count, st);
+        }
+        launch_borders(ctx, pyr, 0, slot0, count, st);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");
         return VOFE_OK;
@@ -522,11 +526,11 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     {
         const VofeLevel& L = pyr->lv[0];
         const int nb = (ww + 15) / 16;                              // mirrored groups per side
-        const char* pc = getenv("VOFE_PAD_COPY");                   // "generic" forces the any-width kernel (tests)
-        if (L.w >= 16 * nb + 17 && !(pc && pc[0] == 'g')) {
+        if (L.w >= 16 * nb + 17 && !ctx->knobs.pad_copy_generic) {   // VOFE_PAD_COPY=generic forces the any-width kernel (tests)
             const int ni = (L.w + 15) / 16;
             const long long items = (long long)(2 * nb + ni) * (L.h + 2 * wh);
             if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+            VOFE_TIMED(ctx, "pad_copy_level0_wide");
             hipLaunchKernelGGL(pad_copy_level0_wide, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img,
                                pitch, img_stride, L, slot0, wh, nb, ni, nb, (int)items);
         } else {
@@ -534,6 +538,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
             const int ngx = gx1 - gx0 + 1;
             const long long items = (long long)ngx * (L.h + 2 * wh);
             if (items > 0x7fffff00ll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+            VOFE_TIMED(ctx, "pad_copy_level0");
             hipLaunchKernelGGL(pad_copy_level0, dim3((unsigned)((items + 255) / 256), count), dim3(256), 0, st, d_img, pitch,
                                img_stride, L, slot0, wh, gx0, ngx, (int)items);
         }
@@ -543,11 +548,12 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         const VofeLevel& D = pyr->lv[l];
         const int gpr = (D.w + 7) / 8;
         const int items = gpr * ((D.h + 1) / 2);
+        VOFE_TIMED(ctx, "pyr_down_u8", l);
         hipLaunchKernelGGL(pyr_down_u8, dim3((items + 255) / 256, count), dim3(256), 0, st, S, D, slot0, gpr, items);
     }
     if (pyr->levels > 1) {
         // border bands of levels 1.. (level 0 got its border from pad_copy_level0: no blocks for it)
-        launch_borders(pyr, 1, slot0, count, st);
+        launch_borders(ctx, pyr, 1, slot0, count, st);
     }
     if (pyr->with_deriv) {
         ScharrPlan plan;
@@ -559,6 +565,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
             total += plan.blk_x[l] * ((pyr->lv[l].h + 3) / 4);
         }
         plan.blk_start[pyr->levels] = total;
+        VOFE_TIMED(ctx, "scharr_deriv_s16x2");
         hipLaunchKernelGGL(scharr_deriv_s16x2, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0);
     }
     hipError_t e = hipGetLastError();

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <climits>
+#include <string>
+#include <vector>
 
 #include "../../include/vofe.h"
 
@@ -20,9 +22,30 @@ struct VofeLevel {
     long long slot_stride;    // pixels between consecutive slots (same for I and D)
 };
 
+// VOFE_* environment switches (tests, tuning, measurements).  Read ONCE per context at vofe_create -- not on the
+// launch paths, whose latency is measured in tens of microseconds -- and again by vofe_reload_env (tests).
+struct VofeKnobs {
+    char lk[8];               // VOFE_LK: "generic" | "x1" | "x2" | "x4" | "" (size rule)
+    char pyramid;             // VOFE_PYRAMID: 'f'used | 'l'evels | 0 (size rule)
+    bool pad_copy_generic;    // VOFE_PAD_COPY=generic: the any-width copy / border kernels
+    bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
+    int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
+    bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
+    bool gftt_debug;          // VOFE_GFTT_DEBUG
+    bool gftt_chain;          // VOFE_GFTT_CHAIN=split: the unmerged detector launch chain
+    int sel_blocks, sel_launches, sel_passes, sel_spins, sel_prefix, sel_full;   // VOFE_SEL_*
+};
+
+// Measurement aid (vofe_profile_begin / vofe_profile_end): while a context profiles, every kernel launch of the
+// streaming stages and the detector is bracketed by two HIP events on the context's stream.
+struct VofeProfEntry { std::string name; hipEvent_t a, b; };
+struct VofeProf { std::vector<VofeProfEntry> entries; };
+
 struct vofe_ctx {
     int device;
     hipStream_t stream;
+    VofeKnobs knobs;
+    VofeProf* prof;           // non-NULL between vofe_profile_begin and vofe_profile_end
     // GFTT workspace (grown on demand)
     void* ws;
     size_t ws_bytes;
@@ -44,7 +67,29 @@ struct vofe_pyr {
 };
 
 void vofe_set_error(const char* fmt, ...);
+void vofe_read_knobs(VofeKnobs* k);
 int vofe_hip_fail(hipError_t e, const char* what);
+
+// brackets the launches issued in its scope with HIP events when the context profiles; otherwise one pointer test
+struct VofeKernelScope {
+    vofe_ctx* c;
+    long idx;
+    VofeKernelScope(vofe_ctx* ctx, const char* name, int level = -1) : c(ctx), idx(-1) {
+        if (!ctx->prof) return;
+        VofeProfEntry e;
+        e.name = name;
+        if (level >= 0) e.name += " L" + std::to_string(level);
+        if (hipEventCreate(&e.a) != hipSuccess) return;
+        if (hipEventCreate(&e.b) != hipSuccess) { hipEventDestroy(e.a); return; }
+        hipEventRecord(e.a, ctx->stream);
+        ctx->prof->entries.push_back(e);
+        idx = (long)ctx->prof->entries.size() - 1;
+    }
+    ~VofeKernelScope() { if (idx >= 0) hipEventRecord(c->prof->entries[idx].b, c->stream); }
+};
+#define VOFE_TIMED_CAT2(a, b) a##b
+#define VOFE_TIMED_CAT(a, b) VOFE_TIMED_CAT2(a, b)
+#define VOFE_TIMED(...) VofeKernelScope VOFE_TIMED_CAT(vofe_scope_, __LINE__)(__VA_ARGS__)
 
 #define VOFE_HIP(call)                                              \
     do {                                                            \
@@ -56,7 +101,7 @@ int vofe_hip_fail(hipError_t e, const char* what);
 int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, const uint8_t* d_img,
                         int pitch, size_t img_stride);
 int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
-                   int next_slot, const float* d_prev_pts, const int* d_img_idx, float* d_next_pts,
+                   int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                    uint8_t* d_status, float* d_err, int n, int max_count, double eps2, int flags,
                    float min_eig_thr, int fb, float fb_thresh);
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,

@@ -31,17 +31,26 @@ _DEFAULT_CRITERIA = (TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01)
 
 
 class Pyramid:
-    """A vofe_pyr: `slots` images of one geometry, all levels + Scharr planes resident in HBM."""
+    """A vofe_pyr: `slots` images of one geometry, all levels + Scharr planes resident in HBM.
+
+    Holds the library handle and the context handle, not the FrontEnd (only a weak reference to it), so that a cached
+    pyramid never keeps its FrontEnd alive; free() still releases the device memory after the context is gone
+    (vofe_pyramid_free accepts a NULL context)."""
 
     def __init__(self, fe, slots, height, width, winSize, maxLevel, with_deriv=True):
-        self.fe = fe
+        self._fe = weakref.ref(fe)
+        self.L, self._ctx = fe.L, fe.ctx
         self.slots, self.height, self.width = int(slots), int(height), int(width)
         self.winSize, self.maxLevel = (int(winSize[0]), int(winSize[1])), int(maxLevel)
         self._h = C.c_void_p()
-        _lib.check(fe.L.vofe_pyramid_create(fe.ctx, self.slots, self.height, self.width, self.winSize[0],
-                                            self.winSize[1], self.maxLevel, int(bool(with_deriv)),
-                                            C.byref(self._h)))
-        self.levels = fe.L.vofe_pyramid_levels(self._h)
+        _lib.check(self.L.vofe_pyramid_create(self._ctx, self.slots, self.height, self.width, self.winSize[0],
+                                              self.winSize[1], self.maxLevel, int(bool(with_deriv)),
+                                              C.byref(self._h)))
+        self.levels = self.L.vofe_pyramid_levels(self._h)
+
+    @property
+    def fe(self):
+        return self._fe()
 
     def build(self, images, slot0=0):
         """images: CUDA uint8 tensor (H,W) or (B,H,W); fills slots slot0..slot0+B-1 (asynchronous)."""
@@ -51,33 +60,34 @@ class Pyramid:
         if t.stride(2) != 1:
             t = t.contiguous()
         stride = t.stride(0) if t.shape[0] > 1 else 0
-        _lib.check(self.fe.L.vofe_pyramid_build(self.fe.ctx, self._h, int(slot0), int(t.shape[0]), t.data_ptr(),
-                                                int(t.stride(1)), int(stride)))
+        _lib.check(self.L.vofe_pyramid_build(self._ctx, self._h, int(slot0), int(t.shape[0]), t.data_ptr(),
+                                             int(t.stride(1)), int(stride)))
         self._keep = t          # keep the source alive until the stream has consumed it
 
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
-        _lib.check(self.fe.L.vofe_pyramid_level_size(self._h, level, C.byref(w), C.byref(h)))
+        _lib.check(self.L.vofe_pyramid_level_size(self._h, level, C.byref(w), C.byref(h)))
         return h.value, w.value
 
     def download(self, slot, level, deriv=False):
         h, w = self.level_size(level)
         img = np.empty((h, w), np.uint8)
         d = np.empty((h, w, 2), np.int16) if deriv else None
-        _lib.check(self.fe.L.vofe_pyramid_download(self.fe.ctx, self._h, slot, level, img.ctypes.data,
-                                                   d.ctypes.data if deriv else None))
+        _lib.check(self.L.vofe_pyramid_download(self._ctx, self._h, slot, level, img.ctypes.data,
+                                                d.ctypes.data if deriv else None))
         return (img, d) if deriv else img
 
     def download_padded(self, slot, level, pad=None):
         px, py = self.winSize if pad is None else pad
         h, w = self.level_size(level)
         img = np.empty((h + 2 * py, w + 2 * px), np.uint8)
-        _lib.check(self.fe.L.vofe_pyramid_download_padded(self.fe.ctx, self._h, slot, level, px, py, img.ctypes.data))
+        _lib.check(self.L.vofe_pyramid_download_padded(self._ctx, self._h, slot, level, px, py, img.ctypes.data))
         return img
 
     def free(self):
-        if self._h and self.fe.ctx:
-            self.fe.L.vofe_pyramid_free(self.fe.ctx, self._h)
+        if self._h:
+            # a context that has already been destroyed is passed as NULL: the planes are freed all the same
+            self.L.vofe_pyramid_free(self._ctx if self._ctx else None, self._h)
         self._h = C.c_void_p()
 
     def __del__(self):
@@ -120,6 +130,10 @@ class FrontEnd:
 
     def synchronize(self):
         _lib.check(self.L.vofe_synchronize(self.ctx))
+
+    def reload_env(self):
+        """Re-read the VOFE_* switches (the library reads them once, at vofe_create).  Test aid."""
+        _lib.check(self.L.vofe_reload_env(self.ctx))
 
     # -------------------------------------------------------------------------------- helpers
     def to_device(self, img):
@@ -220,7 +234,7 @@ class FrontEnd:
             if q.shape != p.shape:
                 raise error(-1, "nextPts must match prevPts with OPTFLOW_USE_INITIAL_FLOW")
             d_next.copy_(torch.from_numpy(q))
-        _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, d_next.data_ptr(),
+        _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, 1, d_next.data_ptr(),
                                         d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
                                         float(criteria[2]), int(flags), float(minEigThreshold)))
         nxt, st, err = self._unpack_outputs(buf, n)
@@ -240,7 +254,7 @@ class FrontEnd:
         pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
         pyr.build(torch.stack([a, b]), 0)
         io = self._points_io(p)
-        _lib.check(self.L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, io["prev"], None, io["next"], io["status"], io["err"],
+        _lib.check(self.L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, io["prev"], None, 1, io["next"], io["status"], io["err"],
                                         n, int(criteria[0]), int(criteria[1]), float(criteria[2]), float(minEigThreshold),
                                         float(fb_thresh)))
         nxt, st, err = self._points_done(io)
@@ -451,9 +465,9 @@ def default_frontend():
 
 
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
-                        useHarrisDetector=False, k=0.04):
+                        useHarrisDetector=False, k=0.04, gradientSize=3):
     return default_frontend().goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
-                                                  useHarrisDetector, k)
+                                                  useHarrisDetector, k, gradientSize)
 
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,

@@ -44,13 +44,17 @@ class SequenceTracker:
             raise error(-1, "prefetch: need a uint8 frame of %dx%d" % (self.w, self.h))
         if self._stage is None:
             self._stage = [torch.empty((self.h, self.w), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._stage_ev = [None, None]
             self._copy_stream = torch.cuda.Stream(device=self.fe.device)
         k = self._stage_k = 1 - self._stage_k
+        if self._stage_ev[k] is not None:
+            self._stage_ev[k].synchronize()                   # the previous upload out of this staging buffer has left it
         self._stage[k].numpy()[...] = a                       # host copy into pinned memory
         with torch.cuda.stream(self._copy_stream):
             d = self._stage[k].to(self.fe.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
+        self._stage_ev[k] = ev
         self._prefetched = (a, d, ev)
 
     def _push(self, img):
@@ -58,6 +62,11 @@ class SequenceTracker:
         if pre is not None and pre[0] is img:
             torch.cuda.current_stream(self.fe.device).wait_event(pre[2])
             d = pre[1]
+            # the frame was allocated on the copy stream: tell the caching allocator which streams consume it, so the
+            # block is not handed to a later side-stream copy while their kernels still read it
+            d.record_stream(torch.cuda.current_stream(self.fe.device))
+            if self._det_stream is not None:
+                d.record_stream(self._det_stream)
             self._uploaded = pre[2]
         else:
             d = self.fe.to_device(img)
@@ -96,7 +105,7 @@ class SequenceTracker:
         if n:
             fe = self.fe
             io = fe._points_io(np.concatenate(flat, 0))
-            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, io["prev"], None, io["next"],
+            _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_slot, self.pyr._h, next_slot, io["prev"], None, 1, io["next"],
                                           io["status"], io["err"], n, self.criteria[0], self.criteria[1], self.criteria[2],
                                           self.min_eig, self.fb_thresh))
         return sets, io, n
@@ -127,6 +136,7 @@ class SequenceTracker:
             self._det_fe = FrontEnd(self.fe.device.index, stream=self._det_stream)
         launched = self._launch(img_current, point_sets)       # upload, pyramid, LK launch: asynchronous
         img = self._img[self.frame_index & 1]
+        img.record_stream(self._det_stream)                   # consumed on the detector's stream as well
         self._det_stream.wait_event(self._uploaded)            # only the upload: not the pyramid or the tracker launch
         with torch.cuda.stream(self._det_stream):
             corners = self._det_fe.goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance, mask=mask,
@@ -169,6 +179,7 @@ class MultiSequenceTracker:
         self.pyr = Pyramid(self.fe, 2 * self.B, self.h, self.w, winSize, maxLevel, True)   # two rings of B slots
         self.frame_index = -1
         self._img = [None, None]
+        self._idx_cache = (None, None)            # (counts, device int32 image index per point) of the last call
 
     def _push(self, frames):
         if isinstance(frames, torch.Tensor):
@@ -208,9 +219,11 @@ class MultiSequenceTracker:
         if n:
             fe = self.fe
             io = fe._points_io(np.concatenate(flat, 0))
-            idx = torch.from_numpy(np.repeat(np.arange(self.B, dtype=np.int32), counts)).to(fe.device)
+            if self._idx_cache[0] != counts:          # the per-point image index changes only when the counts do
+                self._idx_cache = (counts, torch.from_numpy(np.repeat(np.arange(self.B, dtype=np.int32), counts)).to(fe.device))
+            idx = self._idx_cache[1]
             _lib.check(fe.L.vofe_track_fb(fe.ctx, self.pyr._h, prev_ring * self.B, self.pyr._h, next_ring * self.B, io["prev"],
-                                          idx.data_ptr(), io["next"], io["status"], io["err"], n, self.criteria[0],
+                                          idx.data_ptr(), self.B, io["next"], io["status"], io["err"], n, self.criteria[0],
                                           self.criteria[1], self.criteria[2], self.min_eig, self.fb_thresh))
             nxt, st, err = fe._points_done(io)
         out, o = [], 0
