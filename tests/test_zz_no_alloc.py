@@ -1,0 +1,79 @@
+"""vofe_gftt_noalloc (include/vofe.h): the detector entry point that allocates nothing -- its workspace is a static
+device array inside libvofe.so -- against vofe_gftt, the entry point it is a variant of, through the C ABI.
+
+Two calls in a row on one GPU, the second on a smaller frame (the array keeps the first call's contents: whatever
+must start at zero has to be cleared by the call itself), then a second context on the same GPU (it shares the
+array), a masked / Harris call, and the size limit.  Bar: identical corner lists and counts (integer / index work)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from visual_odometry_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _detect(fe, entry, d_img, maxc, q, md, d_mask=None, harris=False, cap=None):
+    import torch
+    h, w = d_img.shape
+    cap = int(cap if cap is not None else (maxc if maxc > 0 else h * w))
+    out = torch.full((max(cap, 1), 2), -7.0, dtype=torch.float32, device=d_img.device)
+    n = C.c_int(-1)
+    rc = getattr(fe.L, entry)(fe.ctx, d_img.data_ptr(), h, w, d_img.stride(0), int(maxc), float(q), float(md),
+                              d_mask.data_ptr() if d_mask is not None else None, 3, 3, int(harris), 0.04,
+                              out.data_ptr(), cap, C.byref(n))
+    return rc, n.value, out.cpu().numpy()
+
+
+def _same(fe, img, maxc, q, md, mask=None, harris=False, cap=None, other=None):
+    import torch
+    d_img = torch.from_numpy(img).cuda()
+    d_mask = torch.from_numpy(mask).cuda() if mask is not None else None
+    rc0, n0, c0 = _detect(fe, "vofe_gftt", d_img, maxc, q, md, d_mask, harris, cap)
+    rc1, n1, c1 = _detect(other or fe, "vofe_gftt_noalloc", d_img, maxc, q, md, d_mask, harris, cap)
+    assert rc0 == 0 and rc1 == 0, fe.L.vofe_last_error()
+    assert n1 == n0
+    assert np.array_equal(c1, c0)               # the filled part AND the untouched tail of the buffer
+    return n0, c0
+
+
+def test_noalloc_detector_equals_vofe_gftt_on_consecutive_calls(fe):
+    from visual_odometry_amd.frontend import FrontEnd
+    big = synthetic.sequence(376, 1241, seed=0, n_frames=1)[0]           # BASELINE configs[1] frame
+    small = synthetic.sequence(120, 160, seed=11, n_frames=1)[0]
+    n_big, c_big = _same(fe, big, 2000, 0.01, 7)
+    ref = oracle.goodFeaturesToTrack(big, 2000, 0.01, 7, nthreads=8).reshape(-1, 2)
+    assert n_big == ref.shape[0] and np.array_equal(c_big[:n_big], ref)
+    # second call, smaller input: stale maps / histograms / counts of the first call must not leak into it
+    n_small, c_small = _same(fe, small, 100, 0.01, 7)
+    ref = oracle.goodFeaturesToTrack(small, 100, 0.01, 7).reshape(-1, 2)
+    assert 0 < n_small == ref.shape[0] and np.array_equal(c_small[:n_small], ref)
+    # and back up again, then a frame with no corner at all
+    _same(fe, big, 1000, 0.01, 10)
+    assert _same(fe, np.full((50, 60), 9, np.uint8), 100, 0.01, 5)[0] == 0
+    # every context of a GPU shares the array: a second context's call in between changes nothing
+    fe2 = FrontEnd(0)
+    _same(fe, small, 0, 0.05, 3, other=fe2)
+    _same(fe, big, 500, 0.01, 0.5)
+    fe2.close()
+    # mask, Harris, a capacity below the count, maxCorners = 0 (unbounded list)
+    mask = np.zeros_like(big)
+    mask[50:300, 200:900] = 255
+    _same(fe, big, 300, 0.01, 8, mask=mask)
+    _same(fe, big, 300, 0.01, 8, harris=True)
+    n, c = _same(fe, big, 400, 0.01, 5, cap=100)
+    assert n == 400 and (c[:100] >= 0).all()
+    malaga = synthetic.sequence(600, 800, seed=1, n_frames=1)[0]          # 480 000 px: the largest reference frame
+    _same(fe, malaga, 0, 0.01, 10)
+
+
+def test_noalloc_detector_rejects_frames_beyond_its_static_workspace(fe):
+    import torch
+    d_img = torch.zeros((725, 725), dtype=torch.uint8, device="cuda")    # 525 625 px > 512 * 1024
+    rc, n, _ = _detect(fe, "vofe_gftt_noalloc", d_img, 10, 0.01, 5)
+    assert rc == -3 and n == 0 and b"VOFE_NOALLOC_MAX_PIXELS" in fe.L.vofe_last_error()
+    d_ok = torch.zeros((512, 1024), dtype=torch.uint8, device="cuda")    # exactly the limit
+    assert _detect(fe, "vofe_gftt_noalloc", d_ok, 10, 0.01, 5)[0] == 0
+    assert _detect(fe, "vofe_gftt_noalloc", d_ok, 10, 0.0, 5)[0] == -1  # the cv2 argument asserts still apply

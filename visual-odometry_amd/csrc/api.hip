@@ -93,6 +93,8 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
     c->lk_counters = nullptr;
     c->prof = nullptr;
     vofe_read_knobs(&c->knobs);
+    int rc = vofe_gftt_setup(c);
+    if (rc) { if (c->h_pinned) hipHostFree(c->h_pinned); delete c; return rc; }
     *out = c;
     return VOFE_OK;
 }
@@ -386,6 +388,24 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
     VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
                           d_corners_xy, capacity, h_n_out);
+}
+
+int vofe_gftt_noalloc(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
+                      int max_corners, double quality, double min_distance, const uint8_t* d_mask,
+                      int block_size, int aperture, int harris, double k, float* d_corners_xy,
+                      int capacity, int* h_n_out) {
+    if (!h_n_out) { vofe_set_error("vofe_gftt_noalloc: h_n_out is NULL"); return VOFE_E_ARG; }
+    *h_n_out = 0;
+    if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0) {
+        vofe_set_error("vofe_gftt_noalloc: need qualityLevel > 0, minDistance >= 0, maxCorners >= 0");
+        return VOFE_E_ARG;
+    }
+    int rc = corner_args("vofe_gftt_noalloc", ctx, d_img, height, width, pitch, block_size, aperture);
+    if (rc) return rc;
+    if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt_noalloc: bad output buffer"); return VOFE_E_ARG; }
+    VOFE_BIND(ctx);
+    return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
+                          d_corners_xy, capacity, h_n_out, nullptr, true);
 }
 
 int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,

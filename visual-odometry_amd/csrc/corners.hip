@@ -799,6 +799,26 @@ __global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __r
     }
 }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Static workspace of vofe_gftt_noalloc (include/vofe.h): the detector's whole workspace for frames of up to
+// VOFE_NOALLOC_MAX_PIXELS pixels as ONE file-scope device array, so that entry point never allocates.  Every GPU the
+// library runs on holds its own copy (at its own address) until the process ends.  `scratch` is only a host-side
+// handle for the symbol: host code never passes it anywhere but to hipGetSymbolAddress; kernels, memsets and copies
+// take the per-device address kept in g_scratch_ptr.
+constexpr size_t NOALLOC_MAX_PX = VOFE_NOALLOC_MAX_PIXELS;
+constexpr size_t NOALLOC_HDR_BYTES = 256;
+static_assert(sizeof(GfttHdr) <= NOALLOC_HDR_BYTES, "one header");
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_HDR_BYTES + 2 * (size_t)N_COPY * N_BUCKET * sizeof(unsigned) +
+                                         NOALLOC_MAX_PX * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+constexpr int VOFE_MAX_DEVICES = 64;
+static void* g_scratch_ptr[VOFE_MAX_DEVICES];        // per device: where THAT device's copy of `scratch` lives
+
+namespace {
+
 int ensure_ws(vofe_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return VOFE_OK;
     if (ctx->ws) { hipStreamSynchronize(ctx->stream); hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
@@ -821,6 +841,20 @@ int ensure_pinned(vofe_ctx* ctx, size_t ints) {
 }
 
 }  // namespace
+
+int vofe_gftt_setup(vofe_ctx* ctx) {
+    // once per device, with that device current (vofe_create has made it so): the device's own address of `scratch`
+    if (ctx->device < 0 || ctx->device >= VOFE_MAX_DEVICES) { vofe_set_error("vofe_create: device index %d beyond %d", ctx->device, VOFE_MAX_DEVICES); return VOFE_E_UNSUPPORTED; }
+    if (!g_scratch_ptr[ctx->device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return vofe_hip_fail(e, "hipGetSymbolAddress(scratch)");
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    // the pinned, device-mapped header every detector call reads its counts from: one image's worth now, so that the
+    // no-allocation entry point finds it in place (batched calls and host corner lists grow it on demand)
+    return ensure_pinned(ctx, sizeof(GfttHdr) / 4);
+}
 
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
@@ -872,7 +906,7 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out, float* h_corners_xy) {
+                   int* h_n_out, float* h_corners_xy, bool noalloc) {
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
@@ -880,8 +914,22 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const size_t hdr_bytes = ((sizeof(GfttHdr) * batch + 255) / 256) * 256;
     const size_t hist_bytes = (size_t)batch * N_COPY * N_BUCKET * sizeof(unsigned);
     const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
-    int rc = ensure_ws(ctx, tot);
-    if (rc) return rc;
+    int rc = VOFE_OK;
+    uint8_t* base = nullptr;
+    if (noalloc) {
+        // the device's static scratch array instead of the context's workspace: nothing is allocated or freed
+        if (batch != 1 || h_corners_xy || px > NOALLOC_MAX_PX || tot > NOALLOC_SCRATCH_BYTES) {
+            vofe_set_error("vofe_gftt_noalloc: %dx%d = %zu pixels exceeds the static workspace (VOFE_NOALLOC_MAX_PIXELS = %zu)",
+                           w, h, px, NOALLOC_MAX_PX);
+            return VOFE_E_UNSUPPORTED;
+        }
+        base = static_cast<uint8_t*>(g_scratch_ptr[ctx->device]);
+        if (!base || ctx->h_pinned_ints < sizeof(GfttHdr) / 4) { vofe_set_error("vofe_gftt_noalloc: context was not set up"); return VOFE_E_HIP; }
+    } else {
+        rc = ensure_ws(ctx, tot);
+        if (rc) return rc;
+        base = static_cast<uint8_t*>(ctx->ws);
+    }
     // pinned staging: headers, then (single image, host output requested) the corner list itself, so that
     // corners and count arrive with the one synchronisation of the call
     const size_t hdr_ints = (sizeof(GfttHdr) / 4) * (size_t)batch;
@@ -892,9 +940,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         stage_floats = (size_t)std::max<long long>(m, 0) * 2;
         if (stage_floats > 2 * (size_t)RANK_MAX) stage_floats = 0;       // unbounded lists are fetched after the count is known
     }
-    rc = ensure_pinned(ctx, hdr_ints + stage_floats);
-    if (rc) return rc;
-    uint8_t* base = static_cast<uint8_t*>(ctx->ws);
+    if (!noalloc) {
+        rc = ensure_pinned(ctx, hdr_ints + stage_floats);
+        if (rc) return rc;
+    }
     GfttHdr* hdr = reinterpret_cast<GfttHdr*>(base);
     unsigned* hist = reinterpret_cast<unsigned*>(base + hdr_bytes);
     unsigned* cursor = reinterpret_cast<unsigned*>(base + hdr_bytes + hist_bytes);
@@ -941,9 +990,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
 
     // header + histogram start a call at zero: bucket_scan leaves them so, a memset is needed only for a fresh or
     // re-laid-out workspace (the layout depends on the batch) or after a call that did not run to its end
-    if (ctx->gftt_clean_batch != batch || ctx->gftt_clean_ws != ctx->ws)
+    // (the static scratch array is shared by every context on the device and keeps the last call's contents: always cleared)
+    if (noalloc || ctx->gftt_clean_batch != batch || ctx->gftt_clean_ws != ctx->ws)
         VOFE_HIP(hipMemsetAsync(base, 0, hdr_bytes + hist_bytes, st));
-    ctx->gftt_clean_batch = 0;
+    if (!noalloc) ctx->gftt_clean_batch = 0;
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
@@ -1029,8 +1079,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         }
         if (pass > 4096) { vofe_set_error("vofe_gftt: selection did not converge"); return VOFE_E_HIP; }
     }
-    ctx->gftt_clean_batch = batch;                 // bucket_scan left max_key and the histograms of this layout at zero
-    ctx->gftt_clean_ws = ctx->ws;
+    if (!noalloc) {
+        ctx->gftt_clean_batch = batch;             // bucket_scan left max_key and the histograms of this layout at zero
+        ctx->gftt_clean_ws = ctx->ws;
+    }
     unsigned nmax = 0;
     for (int b = 0; b < batch; ++b) {
         const unsigned n = hh[b].n_acc;

@@ -68,6 +68,9 @@ struct vofe_pyr {
 
 void vofe_set_error(const char* fmt, ...);
 void vofe_read_knobs(VofeKnobs* k);
+// per-context set-up of the detector (corners.hip): binds the device's copy of the static scratch array
+// (hipGetSymbolAddress, once per device) and allocates the small pinned header buffer every detector call reads back
+int vofe_gftt_setup(vofe_ctx* ctx);
 int vofe_hip_fail(hipError_t e, const char* what);
 
 // brackets the launches issued in its scope with HIP events when the context profiles; otherwise one pointer test
@@ -120,7 +123,7 @@ int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_po
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out, float* h_corners_xy = nullptr);
+                   int* h_n_out, float* h_corners_xy = nullptr, bool noalloc = false);
 
 // ---- device helpers shared by kernels ------------------------------------------------------
 __device__ __forceinline__ int vofe_reflect101(int p, int n) {
