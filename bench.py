@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the feature front end's LK frame on MI355X (BASELINE.json configs[1]).
 
-One "LK frame"  = a synthetic KITTI-shaped pair: Gaussian pyramids + Scharr planes
-of BOTH 1241x376 frames, forward LK of 2000 keypoints (21x21 window, 4 levels, criteria (30, 0.01),
-minEigThreshold 1e-3), backward LK from every forward result and the forward-backward check --
-exactly what ContinuousVO._track_keypoints asks of cv2 per call (reference continuous.py:131-164).
-One step = --batch independent LK frames (default 64) in one pyramid launch set + one LK launch.  Inputs (8 frames, point sets) are resident in HBM before the
-timed region; every step goes through the C ABI (libvofe.so).  N > 1: each rank tracks its own
-independent sequence (seed 100 + rank) -- replicas only, no collective on the data path.
+One "LK frame"  = a synthetic KITTI-shaped pair: Gaussian pyramids + Scharr planes of BOTH 1241x376
+frames, forward LK of 2000 keypoints (21x21 window, 4 levels, criteria (30, 0.01), minEigThreshold 1e-3), backward LK
+from every forward result and the forward-backward check -- exactly what ContinuousVO._track_keypoints asks of cv2 per
+call (reference continuous.py:131-164).  One LAUNCH SET = --batch independent LK frames (default 64): one pyramid
+build of 2 x batch images + ONE tracker launch.  One STEP = --sets launch sets (default 40 = 2560 LK frames, ~55 ms),
+so that the driver's --steps 20 times more than a second.  Inputs are resident in HBM before the timed region; every
+step goes through the C ABI (libvofe.so).
 
-Prints ONE JSON line on rank 0 (see the driver contract): metric / value (whole-job frames/s) /
-roofline (dominant kernel lk_track_kernel, HIP-event timed inside the timed region) /
-cpu_baseline (the CPU oracle, a port, timed on the host cores of this box on a bounded sample).
+Multi-GPU = replicas only (the reference's frame loop main.py:107-118 is strictly sequential, sequences are
+the only unit that shards).  `python bench.py --gpus N` starts N fresh rank processes itself, one per GPU, before
+anything touches a GPU; under torchrun (WORLD_SIZE set) the process is a rank already.  Rank r tracks sequences
+r, r + N, r + 2N, ... (s mod N assignment) of BASELINE configs[3]'s independent KITTI-shaped sequences (seed 100 + s),
+--batch of them per launch set ("weak" scaling: per-GPU work is fixed; --total-sequences 64 shards a fixed 64 instead
+and reports "strong").  No collective on the data path; the process group carries the barrier and the fold of
+(max time, summed frames).
+
+Prints ONE JSON line on rank 0: metric / value (whole-job frames/s) / roofline (dominant kernel: the tracker launch,
+HIP-event timed on its own stream inside the timed region) / roofline_streaming (pyramid, Scharr and score-map kernels,
+HIP-event timed in this run) / pcie_inclusive / hard_motion / cpu_baseline (the CPU oracle, a port, on this box's host
+cores, which also verifies one launch set of the GPU path: "verified").
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,51 +38,167 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_PEAK_IPC = 0.5            # wave64 VALU instructions per cycle per SIMD (SIMD-32: one wave64 instruction per 2 cycles)
+N_SIMD = 1024                  # 256 CUs x 4
 WIN = (21, 21)
 MAX_LEVEL = 3
 CRITERIA = (3, 30, 0.01)
 MIN_EIG = 1e-3
 N_FRAMES = 8
 
-
-# HBM-side bytes of one LK launch, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-# over this very command (profiles/r01_pmc_bench_fetch.txt, r01_pmc_bench_write.txt; KB x 1024), keyed by
-# (pairs per launch, points per pair).  The kernel's loads are narrow (2- and 8-byte gathers), a pattern for
-# which the guide gives no gfx950 FETCH_SIZE correction, so the raw value is reported; it is well below the
-# algorithmic bytes because the patches are served from L2 / MALL.
-LK7_PMC_TRAFFIC_BYTES = {(64, 2000): int((1747015.3 + 7919.3) * 1024), (16, 2000): int((433516.4 + 1810.0) * 1024),
-                         (1, 2000): int((18078.0 + 141.4) * 1024)}
+# Counter figures of the tracker launch that cannot be read inside a run (rocprofv3 --pmc needs a run of its own):
+# SQ_INSTS_VALU, GRBM_GUI_ACTIVE (-> clock) and FETCH_SIZE / WRITE_SIZE per launch of this very command, keyed by
+# (pairs per launch, points per pair).
+LK_PMC = {
+    (64, 2000): {"valu_instr": 673.6e6, "clock_ghz": 2.25, "fetch_kb": 1747015.3, "write_kb": 7919.3,
+                 "source": "profiles/r01_pmc_lk_valu.txt, r01_pmc_bench_fetch.txt, r01_pmc_bench_write.txt"},
+}
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
-    """per point-level (w+1)^2 * (1 + 4) B of template patch, plus (w+1)^2 B of
-    search-image window per Gauss-Newton iteration."""
+    """per point-level (w+1)^2 * (1 + 4) B of template patch, plus (w+1)^2 B of search-image window per
+    Gauss-Newton iteration."""
     px = (win[0] + 1) * (win[1] + 1)
     return point_levels * px * 5 + iterations * px
 
 
-def main():
+def pyramid_level_sizes(h, w, win, max_level):
+    out = [(h, w)]
+    for _ in range(max_level):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        if w <= win[0] or h <= win[1]:
+            break
+        out.append((h, w))
+    return out
+
+
+def streaming_algorithmic_bytes(name, h, w, win, max_level, frames):
+    """SURVEY.md 8d, per launch over `frames` images: unpadded planes, each input read once, each output written once."""
+    lv = pyramid_level_sizes(h, w, win, max_level)
+    px = [a * b for a, b in lv]
+    if name.startswith("pad_copy_level0"):
+        return frames * (px[0] + (h + 2 * win[1]) * (w + 2 * win[0]))          # image in, padded level-0 plane out
+    if name.startswith("pyr_down_u8 L"):
+        k = int(name.split("L")[-1])
+        return frames * (px[k - 1] + px[k])
+    if name.startswith("scharr_deriv"):
+        return frames * 5 * sum(px)
+    if name.startswith("pyramid_borders"):
+        band = sum((a + 2 * win[1]) * (b + 2 * win[0]) - a * b for a, b in lv[1:])
+        return frames * 2 * band                                                  # border bands: read + written
+    if name.startswith("corner_score"):
+        return frames * 5 * px[0]
+    return None
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=64,
-                    help="independent frame pairs per step: one pyramid launch set + one LK launch for all of them")
+                    help="independent frame pairs per launch set: one pyramid build + one tracker launch for all of them")
+    ap.add_argument("--sets", type=int, default=40, help="launch sets per step")
     ap.add_argument("--streams", type=int, default=2,
-                    help="steps in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial steps")
+                    help="launch sets in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial")
     ap.add_argument("--free-overlap", action="store_true",
-                    help="do not order the LK launches of different streams (they then share the CUs)")
+                    help="do not order the tracker launches of different streams (they then share the CUs)")
+    ap.add_argument("--total-sequences", type=int, default=0,
+                    help="> 0: shard this many sequences over the ranks (strong scaling, e.g. 64 = configs[3] as written); "
+                         "0: --batch sequences per GPU (weak scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_streaming / pcie_inclusive / hard_motion")
+    ap.add_argument("--stub", action="store_true",
+                    help="test aid: CPU ranks over gloo with a stub step (exercises launcher, sharding, fold, JSON)")
+    return ap.parse_args(argv)
 
-    import torch
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv):
+    """Parent of `bench.py --gpus N`: N fresh child processes, one per GPU, started before this process has touched a
+    GPU (it never does).  Child r gets RANK = LOCAL_RANK = r and binds device r.  Returns the exit code."""
+    n = args.gpus
+    if not args.stub:
+        import torch
+        have = torch.cuda.device_count()                  # counts devices without initialising them
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible\n" % (n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VOFE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0:
+                rc = rc or (code if code > 0 else 1)
+                for q in pending:                         # a rank died: the others would wait at the barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def generate_sequences(ids, h, w, n_frames):
+    """Frames of sequences `ids` (seed 100 + s), generated by a few worker processes started before any GPU work."""
+    from visual_odometry_amd import synthetic
+    if len(ids) <= 2:
+        return [synthetic.sequence(h, w, 100 + s, n_frames) for s in ids]
+    import multiprocessing as mp
+    workers = max(1, min(8, len(ids), (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return pool.starmap(synthetic.sequence, [(h, w, 100 + s, n_frames) for s in ids])
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from visual_odometry_amd import synthetic, replicas
+    H, W, _, _, _, _ = synthetic.CONFIGS["kitti"]
+    n, B = args.points, max(1, args.batch)
+
+    # ---- which sequences this rank owns ------------------------------------------------------------------------
+    sharded = world > 1 or args.total_sequences > 0
+    if args.total_sequences > 0:
+        my_ids = replicas.shard(args.total_sequences, rank, world)          # strong: a fixed pool, s mod N
+        scaling = "strong"
+    else:
+        my_ids = replicas.shard(B * world, rank, world)                     # weak: B sequences per GPU
+        scaling = "weak"
+    if sharded:
+        B = len(my_ids)
+        if B == 0:
+            raise SystemExit("bench.py: rank %d owns no sequence (%d sequences over %d ranks)" % (rank, args.total_sequences, world))
+
+    if args.stub:
+        return run_stub(args, rank, world, B, scaling, my_ids)
+
+    # frames are generated before the GPU is touched (worker processes)
+    if sharded:
+        seq_frames = generate_sequences(my_ids, H, W, 2)
+    else:
+        seq_frames = None
+        frames = synthetic.sequence(H, W, seed=replicas.sequence_seed(rank, world), n_frames=N_FRAMES)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -79,59 +206,70 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from visual_odometry_amd import synthetic, _lib, replicas
+    from visual_odometry_amd import _lib
     from visual_odometry_amd.frontend import FrontEnd, Pyramid
-    H, W, _, _, _, _ = synthetic.CONFIGS["kitti"]
     fe = FrontEnd(local_rank)
     L = fe.L
     dev = fe.device
-    n, B = args.points, max(1, args.batch)
-    NP = N_FRAMES - 1                                       # frame pairs of the synthetic sequence
-
-    # ---- inputs, resident in HBM ------------------------------------------------------------
-    seed = replicas.sequence_seed(rank, world)
-    frames = synthetic.sequence(H, W, seed=seed, n_frames=N_FRAMES)
-    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
-    pts_host = []
-    for t in range(NP):
-        c = fe.goodFeaturesToTrack(d_frames[t], n, 0.01, 7)
-        pts_host.append(synthetic.pad_points(c, n, H, W, seed + t))
-    d_pts = [torch.from_numpy(p).to(dev) for p in pts_host]
     img_stride = H * W
-    # A step tracks B independent frame pairs (configs[1]: the pairs do not depend on each other).  Phase f
-    # of the input holds pairs (f + k) % NP, k < B, as [B previous frames | B next frames] with the point
-    # sets concatenated and an image index per point.
-    phases = []
-    for f in range(NP):
-        pairs = [(f + k) % NP for k in range(B)]
-        imgs = torch.cat([d_frames[pairs], d_frames[[q + 1 for q in pairs]]]).contiguous()
-        phases.append((imgs, torch.cat([d_pts[q] for q in pairs]).contiguous(), pairs))
+
+    # ---- inputs, resident in HBM ------------------------------------------------------------------------------
+    # A launch set tracks B independent frame pairs laid out as [B previous frames | B next frames], the point sets
+    # concatenated, an image index per point.
+    phases = []             # (images (2B,H,W) u8, points (B*n,2) f32, host pairs [(prev, next, pts)] for verification)
+    if not sharded:
+        # BASELINE configs[1]: the seed-0 KITTI sequence; phase f holds its pairs (f + k) % NP, k < B
+        NP = N_FRAMES - 1
+        d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+        pts_host = []
+        for t in range(NP):
+            c = fe.goodFeaturesToTrack(d_frames[t], n, 0.01, 7)
+            pts_host.append(synthetic.pad_points(c, n, H, W, replicas.sequence_seed(rank, world) + t))
+        d_pts = [torch.from_numpy(p).to(dev) for p in pts_host]
+        for f in range(NP):
+            pairs = [(f + k) % NP for k in range(B)]
+            imgs = torch.cat([d_frames[pairs], d_frames[[q + 1 for q in pairs]]]).contiguous()
+            phases.append((imgs, torch.cat([d_pts[q] for q in pairs]).contiguous(),
+                           [(frames[q], frames[q + 1], pts_host[q]) for q in pairs]))
+    else:
+        # BASELINE configs[3]: slot k of every launch set is the pair (frame 0, frame 1) of this rank's k-th sequence
+        d_prev = torch.from_numpy(np.stack([q[0] for q in seq_frames])).to(dev)
+        d_next = torch.from_numpy(np.stack([q[1] for q in seq_frames])).to(dev)
+        det, cnt = fe.goodFeaturesToTrack_batch(d_prev, n, 0.01, 7)
+        det = det.cpu().numpy()
+        pts_host = [synthetic.pad_points(det[k, :cnt[k]], n, H, W, 100 + s) for k, s in enumerate(my_ids)]
+        frames = seq_frames[0]
+        d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+        d_pts = [torch.from_numpy(pts_host[0]).to(dev)]
+        phases.append((torch.cat([d_prev, d_next]).contiguous(), torch.from_numpy(np.concatenate(pts_host)).to(dev),
+                       [(seq_frames[k][0], seq_frames[k][1], pts_host[k]) for k in range(B)]))
+    NPH = len(phases)
     d_idx = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(n).contiguous()
     NB = n * B
     d_cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 
-    lk_chain = [None]                                       # completion event of the most recent LK launch (any stream)
+    lk_chain = [None]                                       # completion event of the most recent tracker launch (any stream)
 
     class Worker:
-        """A ctx bound to its own HIP stream with its own pyramid object (2*slots images) and outputs."""
-        def __init__(self, stream, pairs):
-            self.stream, self.pairs = stream, pairs
+        """A ctx bound to its own HIP stream with its own pyramid object (2*B slots) and outputs."""
+        def __init__(self, stream):
+            self.stream = stream
             self.k = 0
             self.lk_done = [torch.cuda.Event() for _ in range(4)]
             with torch.cuda.stream(stream):
                 self.fe = FrontEnd(local_rank)
-                self.pyr = Pyramid(self.fe, 2 * pairs, H, W, WIN, MAX_LEVEL, True)
-                self.nxt = torch.empty((n * pairs, 2), dtype=torch.float32, device=dev)
-                self.st = torch.empty(n * pairs, dtype=torch.uint8, device=dev)
-                self.err = torch.empty(n * pairs, dtype=torch.float32, device=dev)
+                self.pyr = Pyramid(self.fe, 2 * B, H, W, WIN, MAX_LEVEL, True)
+                self.nxt = torch.empty((NB, 2), dtype=torch.float32, device=dev)
+                self.st = torch.empty(NB, dtype=torch.uint8, device=dev)
+                self.err = torch.empty(NB, dtype=torch.float32, device=dev)
 
-        def step(self, f, ev=None):
+        def launch_set(self, f, ev=None):
             # reference-call-equivalent: both pyramids of every pair are rebuilt (continuous.py:145-151)
             imgs, pts, _ = phases[f]
             c = self.fe.ctx
             _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 2 * B, imgs.data_ptr(), W, img_stride))
-            # LK launches of different streams run one after the other (two VALU-bound launches sharing the CUs gain
-            # nothing); the bandwidth-bound pyramid kernels of one stream overlap the LK launch of the other
+            # tracker launches of different streams run one after the other (two VALU-bound launches sharing the CUs
+            # gain nothing); the bandwidth-bound pyramid kernels of one stream overlap the tracker launch of the other
             if lk_chain[0] is not None:
                 self.stream.wait_event(lk_chain[0])
             if ev is not None:
@@ -156,8 +294,8 @@ def main():
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
 
         def step_cached(self, t):
-            # frame-level schedule (SequenceTracker): the previous frame's pyramid is still in its
-            # slot, only the new frame's is built.  At the wrap of the short synthetic sequence frame 0 is rebuilt.
+            # frame-level schedule (SequenceTracker): the previous frame's pyramid is still in its slot,
+            # only the new frame's is built.  At the wrap of the short synthetic sequence frame 0 is rebuilt.
             c = self.fe.ctx
             if t == 0:
                 _lib.check(L.vofe_pyramid_build(c, self.pyr._h, 0, 1, d_frames[0].data_ptr(), W, 0))
@@ -167,12 +305,13 @@ def main():
                                        CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
 
     torch.cuda.synchronize()
-    workers = [Worker(torch.cuda.Stream(device=dev), B) for _ in range(max(1, args.streams))]
+    workers = [Worker(torch.cuda.Stream(device=dev)) for _ in range(max(1, args.streams))]
     S = len(workers)
     w0 = workers[0]
+    SETS = max(1, args.sets)
 
-    def step(i, ev=None):
-        workers[i % S].step(i % NP, ev)
+    def launch_set(i, ev=None):
+        workers[i % S].launch_set(i % NPH, ev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,72 +319,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    # tracked keypoints per phase (status == 1 after the forward-backward check), untimed
-    tracked = []
-    for f in range(NP):
-        w0.step(f)
+    for i in range(args.warmup * SETS):
+        launch_set(i)
+    # tracked keypoints per phase (status == 1 after the forward-backward check), untimed; phase 0's outputs are kept
+    # for the verification against the CPU oracle (cpu_baseline leg)
+    tracked, gpu_phase0 = [], None
+    for f in range(NPH):
+        w0.launch_set(f)
         w0.stream.synchronize()
         tracked.append(int(w0.st.sum().item()))
-    # work counters of the LK launch (point-levels, Gauss-Newton iterations): one untimed pass over the
-    # phases, because the counting atomics would slow the timed launches
+        if f == 0:
+            gpu_phase0 = (w0.nxt.cpu().numpy().copy(), w0.st.cpu().numpy().copy(), w0.err.cpu().numpy().copy())
+    # work counters of the tracker launch (point-levels, Gauss-Newton iterations): one untimed pass over the phases,
+    # because the counting atomics would slow the timed launches
     _lib.check(L.vofe_lk_set_counters(w0.fe.ctx, d_cnt.data_ptr()))
-    for f in range(NP):
-        w0.step(f)
+    for f in range(NPH):
+        w0.launch_set(f)
     torch.cuda.synchronize()
     _lib.check(L.vofe_lk_set_counters(w0.fe.ctx, None))
-    cnt_launch = d_cnt.cpu().numpy().astype(np.float64) / NP
-    # HIP events (on the worker's own stream) around every EV_EVERY-th LK launch of the timed region
-    EV_EVERY = 4
+    cnt_launch = d_cnt.cpu().numpy().astype(np.float64) / NPH
+    # HIP events (on the worker's own stream) around every EV_EVERY-th tracker launch of the timed region
+    total_sets = args.steps * SETS
+    EV_EVERY = max(1, total_sets // 100)
     events = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for i in range(0, args.steps, EV_EVERY)}
+              for i in range(0, total_sets, EV_EVERY)}
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events.get(i))
+    for i in range(total_sets):
+        launch_set(i, events.get(i))
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # ---- figures reported beside `value` (this rank only, untimed for the metric) ------------------
-    reps = 200
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(reps):
-        w0.step_one(i % NP)
-    torch.cuda.synchronize()
-    serial_ms = (time.perf_counter() - t1) / reps * 1e3
-    t3 = time.perf_counter()
-    for i in range(reps):
-        w0.step_cached(i % NP)
-    torch.cuda.synchronize()
-    cached_ms = (time.perf_counter() - t3) / reps * 1e3
-    # corner detection on the same geometry (one call per frame in the reference, continuous.py:380-385).
-    # Device-resident image in, corners copied back to the host.
-    gftt_calls = 100
-    for i in range(10):
-        fe.goodFeaturesToTrack(d_frames[i % N_FRAMES], n, 0.01, 7)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for i in range(gftt_calls):
-        fe.goodFeaturesToTrack(d_frames[i % N_FRAMES], n, 0.01, 7)
-    torch.cuda.synchronize()
-    gftt_us = (time.perf_counter() - t2) / gftt_calls * 1e6
-
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
-    tsum = float(sum(tracked[i % NP] for i in range(args.steps)))
-    elapsed, (tsum,) = replicas.fold(dist, dev, elapsed, [tsum])
-
-    frames_total = args.steps * B * world
+    tsum = float(sum(tracked[i % NPH] for i in range(total_sets)))
+    frames_rank = float(total_sets * B)
+    elapsed, (tsum, frames_total) = replicas.fold(dist, dev, elapsed, [tsum, frames_rank])
     fps = frames_total / elapsed
 
     out = None
     if rank == 0:
+        # ---- figures reported beside `value` (rank 0 only, outside the timed region) ------------------------------
+        reps = 200
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(reps):
+            w0.step_one(i % len(d_pts))
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / reps * 1e3
+        cached_ms = None
+        if not sharded:
+            t3 = time.perf_counter()
+            for i in range(reps):
+                w0.step_cached(i % NP)
+            torch.cuda.synchronize()
+            cached_ms = (time.perf_counter() - t3) / reps * 1e3
+        # corner detection on the same geometry (one call per frame in the reference, continuous.py:380-385):
+        # device-resident image in, corners delivered to the host
+        gftt_calls = 100
+        nfr = d_frames.shape[0]
+        for i in range(10):
+            fe.goodFeaturesToTrack(d_frames[i % nfr], n, 0.01, 7)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(gftt_calls):
+            fe.goodFeaturesToTrack(d_frames[i % nfr], n, 0.01, 7)
+        torch.cuda.synchronize()
+        gftt_us = (time.perf_counter() - t2) / gftt_calls * 1e6
+
         alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_launch[1]), float(cnt_launch[2]))
-        achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
-        kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if B * n >= 4000 else "lk_track_kernel<7, 21>"
+        hbm_achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        x2 = NB >= 4000
+        kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if x2 else "lk_track_kernel<7, 21>"
         kernel = "%s: fwd + bwd + FB check of %d pairs x %d points in one launch" % (kname, B, n)
+        pmc = LK_PMC.get((B, n))
+        roof = {"kernel": kernel, "avg_launch_ms": round(lk_ms, 5),
+                "point_levels_per_launch": float(cnt_launch[1]), "gn_iterations_per_launch": float(cnt_launch[2])}
+        hbm = {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": round(hbm_achieved / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
+               "traffic": int((pmc["fetch_kb"] + pmc["write_kb"]) * 1024) if pmc else None,
+               "note": "informational: the window patches are served from L2 / Infinity Cache, so counter traffic is "
+                       "well below the algorithmic bytes (SURVEY 8d: point-levels*(w+1)^2*5 + iterations*(w+1)^2); "
+                       "traffic = PMC FETCH_SIZE + WRITE_SIZE, raw (narrow 2/8/12-byte gathers: no gfx950 correction "
+                       "is calibrated for that access shape)"}
+        if pmc and lk_ms > 0:
+            # the launch is bound by VALU issue: instructions per launch from the PMC pass of this launch shape,
+            # duration live, clock from that pass (GRBM_GUI_ACTIVE / duration)
+            ipc = pmc["valu_instr"] / N_SIMD / (lk_ms * 1e-3 * pmc["clock_ghz"] * 1e9)
+            roof.update({"bound": "valu", "achieved": round(ipc, 4), "peak": VALU_PEAK_IPC,
+                         "unit": "VALU instr/cycle/SIMD", "frac": round(ipc / VALU_PEAK_IPC, 4),
+                         "traffic": hbm["traffic"], "valu_instructions_per_launch": pmc["valu_instr"],
+                         "clock_ghz": pmc["clock_ghz"], "pmc_source": pmc["source"],
+                         "mix_bound_note": "the kernel's instructions are mostly the half-rate class (v_dot2_i32_i16, "
+                                           "v_mad_i32_i24, v_add3, DPP adds: 4.1-4.2 cycles each in isolation, "
+                                           "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD",
+                         "hbm": hbm})
+        else:
+            roof.update(hbm)
         out = {
             "metric": "frames/sec (LK frame: 2 pyramids + fwd/bwd LK + FB check; KITTI 1241x376, 2k pts)",
             "value": round(fps, 2),
@@ -255,46 +425,38 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8/int32 bilinear + int64 window sums, f32 2x2 solve",
             "data": "synthetic (seeded band-limited texture, KITTI-like warp + N(0,1.5) noise; SURVEY 8d)",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
-                                   "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
-                                   "reference-call-equivalent (both pyramids rebuilt per pair)" % n,
-                       "frames_per_step": B, "points": n, "sequences": world, "streams_per_gpu": S,
-                       "parallelism": "replicas only (one sequence per GPU); a step is %d independent frame pairs in one "
-                                      "launch set, %d steps in flight per GPU" % (B, S)},
+            "config": {"workload": ("BASELINE.json configs[3]: independent synthetic KITTI-shaped 1241x376 sequences (seed 100 + s), "
+                                    "sequence s on rank s mod N, %d per GPU, %d keypoints each, 21x21 window, 4 levels" % (B, n))
+                                   if sharded else
+                                   ("BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
+                                    "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
+                                    "reference-call-equivalent (both pyramids rebuilt per pair)" % n),
+                       "frames_per_launch_set": B, "launch_sets_per_step": SETS, "frames_per_step": B * SETS * world,
+                       "points": n, "sequences": B * world if sharded else 1, "streams_per_gpu": S,
+                       "parallelism": "replicas only: sequences sharded s mod N over %d GPU(s), no collective on the data path; "
+                                      "a launch set is %d independent frame pairs, %d launch sets in flight per GPU" % (world, B, S)},
+            "timed_seconds": round(elapsed, 4),
             "single_pair_serial_ms": round(serial_ms, 4),
-            "single_pair_serial_cached_pyramid_ms": round(cached_ms, 4),
+            "single_pair_serial_cached_pyramid_ms": round(cached_ms, 4) if cached_ms is not None else None,
             "cached_pyramid_note": "same LK work, one pyramid built per new frame (SequenceTracker schedule); serial, this rank",
             "gftt_us_per_call": round(gftt_us, 1),
             "gftt_config": "goodFeaturesToTrack(1241x376, maxCorners=%d, qualityLevel=0.01, minDistance=7), serial calls" % n,
             "tracked_keypoints_per_s": round(tsum / elapsed, 1),
             "attempted_points_per_s": round(frames_total * n / elapsed, 1),
-            "roofline": {
-                "kernel": kernel,
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": PEAK_HBM_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": LK7_PMC_TRAFFIC_BYTES.get((B, n)),
-                "avg_launch_ms": round(lk_ms, 5),
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "point_levels_per_launch": float(cnt_launch[1]),
-                "gn_iterations_per_launch": float(cnt_launch[2]),
-                "valu_cycles_per_instruction": 4.27,
-                "valu_note": "profiles/r01_pmc_lk_valu.txt + r01_ubench_valu_rates.txt: the launch issues one VALU instruction per "
-                             "4.27 cycles per SIMD for its whole duration; the instructions that dominate it (v_dot2, v_mul_i32_i24, "
-                             "v_add3, DPP adds) measure 4.1-4.2 cycles each in isolation, plain 2-operand ops 2.4",
-                "note": "VALU-issue bound, not HBM (DESIGN.md 4/5): patches are L2/MALL resident, so the HBM fraction is "
-                        "informational; bytes = point-levels*(w+1)^2*5 + iterations*(w+1)^2; traffic = PMC FETCH_SIZE + "
-                        "WRITE_SIZE of this launch shape (profiles/r01_pmc_bench_*.txt)",
-            },
+            "roofline": roof,
         }
+        if not args.no_extras:
+            out["roofline_streaming"] = streaming_rooflines(torch, fe, _lib, Pyramid, phases[0][0], H, W)
+            out["pcie_inclusive"] = pcie_inclusive(fe, frames, pts_host[0], H, W, n)
+            out["hard_motion"] = hard_motion(torch, fe, _lib, Pyramid, H, W, n, min(B, 64), d_cnt)
+        out["verified"] = None
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(frames, pts_host, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(phases[0][2], gpu_phase0, n, args.cpu_seconds)
+            out["verified"] = out["cpu_baseline"].pop("verified")
     for wk in workers:
         wk.pyr.free()
         wk.fe.close()
@@ -304,30 +466,225 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+    return 0
 
 
-def cpu_baseline(frames, pts, seconds):
-    """The CPU oracle (a port of the OpenCV path, kind 'port') on this box's host cores, same workload,
-    bounded sample.  Reported beside the GPU number; it is not the thing measured above."""
+# ------------------------------------------------------------------------------------------------ extras (rank 0)
+def streaming_rooflines(torch, fe, _lib, Pyramid, imgs, H, W):
+    """The HBM-bound kernels on the launch bench.py's steps make (2 x batch KITTI frames per launch), each bracketed
+    by HIP events on the context's stream (vofe_profile_begin / vofe_profile_end); bytes per SURVEY 8d."""
+    L = fe.L
+    frames = int(imgs.shape[0])
+    pyr = Pyramid(fe, frames, H, W, WIN, MAX_LEVEL, True)
+    score = torch.empty((frames, H, W), dtype=torch.float32, device=imgs.device)
+    reps = 10
+
+    def once():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, frames, imgs.data_ptr(), W, H * W))
+        _lib.check(L.vofe_corner_score(fe.ctx, imgs.data_ptr(), frames, H, W, W, H * W, 3, 3, 0, 0.04, score.data_ptr()))
+    for _ in range(3):
+        once()
+    fe.synchronize()
+    _lib.check(L.vofe_profile_begin(fe.ctx))
+    for _ in range(reps):
+        once()
+    cap = 64 * reps
+    names = C.create_string_buffer(cap * 48)
+    ms = (C.c_float * cap)()
+    cnt = C.c_int(0)
+    _lib.check(L.vofe_profile_end(fe.ctx, cap, names, ms, C.byref(cnt)))
+    acc = {}
+    for i in range(cnt.value):
+        nm = names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
+        acc.setdefault(nm, []).append(ms[i])
+    pyr.free()
+    out = []
+    for nm, ts in acc.items():
+        t = float(np.mean(ts))
+        b = streaming_algorithmic_bytes(nm, H, W, WIN, MAX_LEVEL, frames)
+        e = {"kernel": nm, "frames_per_launch": frames, "avg_launch_ms": round(t, 5), "launches_timed": len(ts)}
+        if b is not None and t > 0:
+            gbs = b / (t * 1e-3) / 1e9
+            e.update({"bound": "hbm", "algorithmic_bytes_per_launch": int(b), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                      "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        out.append(e)
+    return out
+
+
+def pcie_inclusive(fe, frames, pts, H, W, n):
+    """Host arrays in, host arrays out, as the reference hands them over (continuous.py:145-151, main.py:70-79): the
+    new image goes up, (nextPts, status, err) come back.  Never `value`."""
+    from visual_odometry_amd.sequence import SequenceTracker
+    kp = np.ascontiguousarray(pts.T)
+    nf = len(frames)
+    reps = 100
+    for i in range(5):
+        fe.track_keypoints(kp, frames[i % (nf - 1)], frames[i % (nf - 1) + 1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        fe.track_keypoints(kp, frames[i % (nf - 1)], frames[i % (nf - 1) + 1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG)
+    per_call = (time.perf_counter() - t0) / reps
+    trk = SequenceTracker(H, W, WIN, MAX_LEVEL, CRITERIA, MIN_EIG, frontend=fe)
+    trk.reset(frames[0])
+    for i in range(5):
+        trk.track(frames[(i + 1) % nf], kp)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        trk.track(frames[(i + 1) % nf], kp)
+    cached = (time.perf_counter() - t0) / reps
+    trk.close()
+    for i in range(5):
+        fe.goodFeaturesToTrack(frames[i % nf], n, 0.01, 7)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        fe.goodFeaturesToTrack(frames[i % nf], n, 0.01, 7)
+    det = (time.perf_counter() - t0) / reps
+    return {"track_keypoints_us": round(per_call * 1e6, 1), "track_keypoints_frames_per_s": round(1.0 / per_call, 1),
+            "sequence_tracker_track_us": round(cached * 1e6, 1), "sequence_tracker_frames_per_s": round(1.0 / cached, 1),
+            "goodFeaturesToTrack_us": round(det * 1e6, 1),
+            "note": "serial calls with numpy in / numpy out through frontend.py: track_keypoints uploads both 1241x376 frames "
+                    "and rebuilds both pyramids (reference-call-equivalent); SequenceTracker.track uploads the new frame "
+                    "only and builds one pyramid; %d points, results read back" % kp.shape[1]}
+
+
+def hard_motion(torch, fe, _lib, Pyramid, H, W, n, B, d_cnt):
+    """Informational: the same launch on a harder sequence (24 px/frame flow + 1 %/frame zoom -> 10-40 px, 5 % of each
+    frame occluded), so the sensitivity of the headline to the Gauss-Newton iteration count is on record."""
+    from visual_odometry_amd import synthetic
+    L = fe.L
+    fr = synthetic.sequence(H, W, seed=0, n_frames=N_FRAMES, shift=(22.0, 9.0), zoom=0.01, occlusion=0.05, margin=232)
+    d_fr = torch.from_numpy(np.stack(fr)).to(fe.device)
+    NP = N_FRAMES - 1
+    pts = []
+    for t in range(NP):
+        pts.append(synthetic.pad_points(fe.goodFeaturesToTrack(d_fr[t], n, 0.01, 7), n, H, W, t))
+    pairs = [k % NP for k in range(B)]
+    imgs = torch.cat([d_fr[pairs], d_fr[[q + 1 for q in pairs]]]).contiguous()
+    d_p = torch.from_numpy(np.concatenate([pts[q] for q in pairs])).to(fe.device)
+    idx = torch.arange(B, dtype=torch.int32, device=fe.device).repeat_interleave(n).contiguous()
+    NB = n * B
+    nxt = torch.empty((NB, 2), dtype=torch.float32, device=fe.device)
+    st = torch.empty(NB, dtype=torch.uint8, device=fe.device)
+    err = torch.empty(NB, dtype=torch.float32, device=fe.device)
+    pyr = Pyramid(fe, 2 * B, H, W, WIN, MAX_LEVEL, True)
+
+    def once():
+        _lib.check(L.vofe_pyramid_build(fe.ctx, pyr._h, 0, 2 * B, imgs.data_ptr(), W, H * W))
+        _lib.check(L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, B, d_p.data_ptr(), idx.data_ptr(), B, nxt.data_ptr(),
+                                   st.data_ptr(), err.data_ptr(), NB, CRITERIA[0], CRITERIA[1], CRITERIA[2], MIN_EIG, 1.0))
+    d_cnt.zero_()
+    _lib.check(L.vofe_lk_set_counters(fe.ctx, d_cnt.data_ptr()))
+    once()
+    fe.synchronize()
+    _lib.check(L.vofe_lk_set_counters(fe.ctx, None))
+    c = d_cnt.cpu().numpy().astype(np.float64)
+    tracked = float(st.sum().item()) / NB
+    for _ in range(3):
+        once()
+    fe.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    fe.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    pyr.free()
+    return {"frames_per_s": round(B / dt, 1), "ms_per_launch_set": round(dt * 1e3, 4), "frames_per_launch_set": B,
+            "gn_iterations_per_point": round(c[2] / max(c[0], 1), 2), "level_passes_per_point": round(c[1] / max(c[0], 1), 2),
+            "tracked_fraction": round(tracked, 4), "streams": 1,
+            "motion": "22 x 9 px per frame translation + 1 % per frame zoom (flow 10-40 px), 5 % of every frame occluded, N(0,1.5) noise"}
+
+
+def cpu_baseline(pairs, gpu_phase0, n, seconds):
+    """The CPU oracle (a port of the OpenCV path, kind 'port') on this box's host cores, same workload, bounded sample.
+    Reported beside the GPU number, never the thing measured above.  Its first results double as the checker of the
+    run: every pair of launch set 0 of the GPU path is compared with the oracle's triple ("verified")."""
     import oracle
     threads = max(1, min(16, os.cpu_count() or 1))
+    distinct = {}
+    for k, (a, b, p) in enumerate(pairs):                      # configs[1] repeats its 7 pairs over the 64 slots
+        distinct.setdefault((id(a), id(b), id(p)), (a, b, p, []))[3].append(k)
+    work = list(distinct.values())
+
+    def track(a, b, p, nthreads):
+        return oracle.track_keypoints(p.T, a, b, WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, nthreads)
+
+    # verification (untimed): GPU launch set 0 against the oracle, pair by pair
+    g_nxt, g_st, g_err = gpu_phase0
+    checked, exact, status_equal, max_dpos = 0, True, 1.0, 0.0
+    for a, b, p, slots in work:
+        t0_, s0_, e0_ = track(a, b, p, threads)
+        for k in slots:
+            o = k * n
+            gs, gn, ge = g_st[o:o + n], g_nxt[o:o + n].T, g_err[o:o + n]
+            status_equal = min(status_equal, float(np.mean(gs == s0_)))
+            ok = (gs == 1) & (s0_ == 1)
+            if ok.any():
+                max_dpos = max(max_dpos, float(np.abs(gn - t0_)[:, ok].max()))
+            exact = exact and np.array_equal(gs, s0_) and np.array_equal(gn, t0_) and np.array_equal(ge, e0_)
+            checked += 1
+    verified = bool(status_equal >= 0.995 and max_dpos <= 0.05)
 
     def run(nthreads, budget):
         done, t0 = 0, time.perf_counter()
         while True:
-            t = done % (len(frames) - 1)
-            oracle.track_keypoints(pts[t].T, frames[t], frames[t + 1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, nthreads)
+            a, b, p, _ = work[done % len(work)]
+            track(a, b, p, nthreads)
             done += 1
             dt = time.perf_counter() - t0
             if dt >= budget and done >= 3:
                 return done / dt, done
-    oracle.track_keypoints(pts[0].T, frames[0], frames[1], WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, threads)   # warm-up
     fps_mt, n_mt = run(threads, seconds * 0.6)
     fps_1, n_1 = run(1, seconds * 0.4)
     return {"value": round(fps_mt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d LK frames of the same workload (oracle/vofe_oracle.cpp, std::thread over points)" % n_mt,
             "single_thread_value": round(fps_1, 3), "single_thread_sample_frames": n_1,
-            "host_cpu_count": os.cpu_count()}
+            "host_cpu_count": os.cpu_count(),
+            "verified": {"ok": verified, "bit_exact": bool(exact), "pairs_checked": checked,
+                         "min_status_agreement": round(status_equal, 6), "max_position_difference_px": max_dpos,
+                         "what": "every frame pair of one launch set of the timed GPU path (outputs taken before the timed "
+                                 "region) against oracle.track_keypoints; bars 99.5 % status, 0.05 px"}}
+
+
+# ------------------------------------------------------------------------------------------------ stub rank (CPU test)
+def run_stub(args, rank, world, B, scaling, my_ids):
+    """`--stub`: the rank logic without a GPU -- gloo process group, a sleep for a launch set -- so the launcher, the
+    sharding, the barrier / fold and the JSON line are exercised by the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    from visual_odometry_amd import replicas
+    d = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+        dist.barrier()
+    total_sets = args.steps * max(1, args.sets)
+    t0 = time.perf_counter()
+    for _ in range(total_sets):
+        time.sleep(0.0005)
+    if d is not None:
+        d.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, (frames_total, id_sum) = replicas.fold(d, torch.device("cpu"), elapsed, [float(total_sets * B), float(sum(my_ids))])
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (stub)", "value": round(frames_total / elapsed, 2), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
+                          "stub": True, "frames_total": frames_total, "sequence_id_sum": id_sum,
+                          "sequences_rank0": my_ids[:4], "sequences_per_rank": B}), flush=True)
+    if d is not None:
+        d.barrier()
+        d.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

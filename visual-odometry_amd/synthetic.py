@@ -24,22 +24,35 @@ def _canvas(h, w, rng):
     return np.clip((acc - lo) / (hi - lo), 0.0, 1.0) * 255.0
 
 
-def sequence(h, w, seed=0, n_frames=2, noise_sigma=1.5):
-    """Frames t = 0..n_frames-1: canvas sampled under translation (1.5t, 0.4t) px + zoom 1+0.002t
-    about the image centre + N(0, noise_sigma) sensor noise, rounded to u8."""
+def sequence(h, w, seed=0, n_frames=2, noise_sigma=1.5, shift=(1.5, 0.4), zoom=0.002, occlusion=0.0, margin=32):
+    """Frames t = 0..n_frames-1: canvas sampled under translation shift*t px + zoom 1+zoom*t about the image centre
+    + N(0, noise_sigma) sensor noise, rounded to u8.  The defaults are SURVEY 8d's KITTI-like motion (1.5, 0.4) px
+    per frame.  occlusion > 0 (harder-motion variant of bench.py): in every frame after the first, rectangles that
+    cover about that fraction of the frame are replaced by unrelated texture, so the points under them cannot be
+    tracked.  `margin` = canvas border in pixels (enlarge it for large shifts; out-of-canvas samples are mirrored)."""
     from scipy.ndimage import map_coordinates
     rng = np.random.default_rng(seed)
-    canvas = _canvas(h + 64, w + 64, rng)
+    canvas = _canvas(h + 2 * margin, w + 2 * margin, rng)
     ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
     cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
     frames = []
     for t in range(n_frames):
-        z = 1.0 + 0.002 * t
-        sx = (xs - cx) / z + cx + 1.5 * t + 32.0
-        sy = (ys - cy) / z + cy + 0.4 * t + 32.0
+        z = 1.0 + zoom * t
+        sx = (xs - cx) / z + cx + shift[0] * t + float(margin)
+        sy = (ys - cy) / z + cy + shift[1] * t + float(margin)
         f = map_coordinates(canvas, [sy, sx], order=1, mode="reflect")
         f = f + rng.normal(0.0, noise_sigma, f.shape)
         frames.append(np.clip(np.rint(f), 0, 255).astype(np.uint8))
+    if occlusion > 0:
+        orng = np.random.default_rng(seed + 104729)
+        other = _canvas(h, w, orng)
+        for t in range(1, n_frames):
+            covered = 0
+            while covered < occlusion * h * w:
+                rh, rw = int(orng.integers(20, 80)), int(orng.integers(20, 120))
+                y0, x0 = int(orng.integers(0, max(1, h - rh))), int(orng.integers(0, max(1, w - rw)))
+                frames[t][y0:y0 + rh, x0:x0 + rw] = np.clip(np.rint(other[y0:y0 + rh, x0:x0 + rw]), 0, 255).astype(np.uint8)
+                covered += rh * rw
     return frames
 
 
