@@ -47,11 +47,11 @@ MIN_EIG = 1e-3
 N_FRAMES = 8
 
 # Counter figures of the tracker launch that cannot be read inside a run (rocprofv3 --pmc needs a run of its own):
-# SQ_INSTS_VALU, GRBM_GUI_ACTIVE (-> clock) and FETCH_SIZE / WRITE_SIZE per launch of this very command, keyed by
-# (pairs per launch, points per pair).
+# SQ_INSTS_VALU, GRBM_GUI_ACTIVE (cycles) and FETCH_SIZE / WRITE_SIZE per launch of exactly this launch shape
+# (tools/pmc_workload.py under tools/pmc_passes.sh), keyed by (pairs per launch, points per pair).
 LK_PMC = {
-    (64, 2000): {"valu_instr": 673.6e6, "clock_ghz": 2.25, "fetch_kb": 1747015.3, "write_kb": 7919.3,
-                 "source": "profiles/r01_pmc_lk_valu.txt, r01_pmc_bench_fetch.txt, r01_pmc_bench_write.txt"},
+    (64, 2000): {"valu_instr": 651.0e6, "cycles": 22137155.0 / 8, "fetch_kb": 1725226.4, "write_kb": 6170.2,
+                 "source": "profiles/r02_pmc_inst.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r02_pmc_fetch.txt, r02_pmc_write.txt"},
 }
 
 
@@ -403,13 +403,14 @@ def run_rank(args):
                        "traffic = PMC FETCH_SIZE + WRITE_SIZE, raw (narrow 2/8/12-byte gathers: no gfx950 correction "
                        "is calibrated for that access shape)"}
         if pmc and lk_ms > 0:
-            # the launch is bound by VALU issue: instructions per launch from the PMC pass of this launch shape,
-            # duration live, clock from that pass (GRBM_GUI_ACTIVE / duration)
-            ipc = pmc["valu_instr"] / N_SIMD / (lk_ms * 1e-3 * pmc["clock_ghz"] * 1e9)
+            # the launch is bound by VALU issue: instructions and cycles per launch from the counter pass of this launch
+            # shape (clock-free); the live HIP-event duration says what clock those cycles ran at in this run
+            ipc = pmc["valu_instr"] / N_SIMD / pmc["cycles"]
             roof.update({"bound": "valu", "achieved": round(ipc, 4), "peak": VALU_PEAK_IPC,
                          "unit": "VALU instr/cycle/SIMD", "frac": round(ipc / VALU_PEAK_IPC, 4),
                          "traffic": hbm["traffic"], "valu_instructions_per_launch": pmc["valu_instr"],
-                         "clock_ghz": pmc["clock_ghz"], "pmc_source": pmc["source"],
+                         "cycles_per_launch": pmc["cycles"], "implied_clock_ghz": round(pmc["cycles"] / (lk_ms * 1e-3) / 1e9, 3),
+                         "pmc_source": pmc["source"],
                          "mix_bound_note": "the kernel's instructions are mostly the half-rate class (v_dot2_i32_i16, "
                                            "v_mad_i32_i24, v_add3, DPP adds: 4.1-4.2 cycles each in isolation, "
                                            "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD",
