@@ -141,11 +141,11 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
 
 /* vofe_gftt for callers that cannot allocate (code under HIP graph capture set-up, tight serving loops, harnesses
  * that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same results as vofe_gftt, but the
- * detector's workspace (score map, candidate maps, bucket histograms, keys: 22 bytes per pixel + 129 KiB) is a static
+ * detector's workspace (score map, candidate maps, bucket histograms, keys: 27 bytes per pixel + 129 KiB) is a static
  * device array inside the library instead of a buffer grown with hipMalloc, and the call itself allocates and frees
  * nothing (the array's address and the small pinned count header are set up by vofe_create).
  * Limit: height * width <= VOFE_NOALLOC_MAX_PIXELS (covers the reference's 640x480, 1241x376 and 800x600 frames);
- * larger frames are rejected with VOFE_E_UNSUPPORTED.  The array (11.7 MB) is held by every GPU the library runs on
+ * larger frames are rejected with VOFE_E_UNSUPPORTED.  The array (14.3 MB) is held by every GPU the library runs on
  * until the process ends, keeps the previous call's contents (the call clears what must start at zero) and is shared
  * by ALL contexts of a GPU: calls that overlap in time on one GPU race -- serialise them. */
 #define VOFE_NOALLOC_MAX_PIXELS (512 * 1024)

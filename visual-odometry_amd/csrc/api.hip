@@ -39,7 +39,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->score_rs = env_int("VOFE_SCORE_RS", 0);
     k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
-    k->gftt_chain = env_is("VOFE_GFTT_CHAIN", 's');
+    if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : 0;
     k->sel_blocks = env_int("VOFE_SEL_BLOCKS", 1024);
     k->sel_launches = env_int("VOFE_SEL_LAUNCHES", 1);
     k->sel_passes = env_int("VOFE_SEL_PASSES", 2);
@@ -89,7 +89,7 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out) {
     c->stream = (hipStream_t)hip_stream;
     c->ws = nullptr; c->ws_bytes = 0;
     c->h_pinned = nullptr; c->d_pinned = nullptr; c->h_pinned_ints = 0;
-    c->gftt_clean_batch = 0; c->gftt_clean_ws = nullptr;
+    c->gftt_clean_batch = 0; c->gftt_clean_ws = nullptr; c->gftt_last_ncand = 0;
     c->lk_counters = nullptr;
     c->prof = nullptr;
     vofe_read_knobs(&c->knobs);

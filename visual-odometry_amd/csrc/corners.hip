@@ -33,6 +33,7 @@ constexpr int BUCKET_BITS = 14;                 // (bucket << 2 | state) must fi
 static_assert(BUCKET_BITS <= 14, "bucket index is stored in 14 bits");
 constexpr int N_BUCKET = 1 << BUCKET_BITS;      // score buckets of the coarse rank order (fine: few atomics collide)
 
+constexpr size_t GFTT_BYTES_PER_PX = 8 + 4 + 4 + 4 + 4 + 2 + 1;   // workspace maps per pixel (vofe_gftt_impl)
 constexpr int MAX_SLOTS = 32;
 struct GfttHdr {
     unsigned max_key[MAX_SLOTS];   // order-preserving key of the global score maximum (0 = none), spread over slots:
@@ -42,6 +43,8 @@ struct GfttHdr {
     unsigned pad;
     unsigned undecided[SELECT_ROUNDS];
     unsigned seg_end[N_SEG];    // prefix lengths of the bucket-ordered candidate list (bucket boundaries)
+    unsigned fin_state;         // finish_small: 1 = corners emitted, 2 = prefix too long for one block (host runs the split chain)
+    unsigned bm_mb, bm_shift;   // the call's BucketMap (bucket_scan keeps it: max_key is zeroed for the next call)
 };
 
 // Coarse rank order: bucket 0 holds the highest scores.  Buckets partition the positive-float bit
@@ -342,8 +345,83 @@ constexpr int NMS_ROWS = 8;      // rows per thread: a 256-thread block covers 6
 constexpr int N_COPY = 1;        // measured: more copies do not speed the atomics up, they only lengthen the scan
 __device__ __forceinline__ unsigned tile_copy(int x, int y) { return (unsigned)((x >> 6) + (y >> 5)) & (N_COPY - 1); }
 
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of the bucket histogram in (bucket, copy) order: one 1024-thread block per image,
+// N_BUCKET/1024 consecutive buckets per thread -> scatter cursors, the candidate count, and the
+// prefix lengths seg_end[k] = first bucket boundary >= min(n, base << k) (base = 0: everything).
+static_assert(N_COPY == 1, "the scan below handles one histogram copy");
+template <int NT>
+__device__ __forceinline__ void bucket_scan_body(unsigned* __restrict__ hist_img, unsigned* __restrict__ cursor_img,
+                                                 GfttHdr* __restrict__ hd, unsigned base, unsigned full_ratio, double quality,
+                                                 unsigned* s_w, unsigned* s_n) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (wv == 0) {                                       // the call's bucket map, for the one-block last stage
+        unsigned mk = hd->max_key[lane & (MAX_SLOTS - 1)];
+        for (int o = MAX_SLOTS / 2; o > 0; o >>= 1) mk = max(mk, (unsigned)__shfl_xor((int)mk, o));
+        const BucketMap bm = bucket_map(mk, gftt_threshold(mk, quality));
+        if (lane == 0) { hd->bm_mb = bm.mb; hd->bm_shift = bm.shift; }
+    }
+    constexpr int BPT = N_BUCKET / NT;                   // consecutive buckets per thread
+    static_assert(BPT % 4 == 0, "uint4 access");
+    unsigned cnt[BPT];
+    unsigned mine = 0;
+#pragma unroll
+    for (int i = 0; i < BPT / 4; ++i) {
+        const uint4 v = reinterpret_cast<const uint4*>(hist_img)[t * (BPT / 4) + i];
+        cnt[4 * i] = v.x; cnt[4 * i + 1] = v.y; cnt[4 * i + 2] = v.z; cnt[4 * i + 3] = v.w;
+        mine += v.x + v.y + v.z + v.w;
+        // the histogram has been consumed: leave it zero for the next call (no memset command per call)
+        reinterpret_cast<uint4*>(hist_img)[t * (BPT / 4) + i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // likewise the header fields the next call expects to be zero; max_key was last read by the NMS kernel, the accepted
+    // count and the round flags are first touched by the selection that follows this kernel
+    if (t < SELECT_ROUNDS) hd->undecided[t] = 0u;
+    if (t == SELECT_ROUNDS) hd->n_acc = 0u;
+    unsigned inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    if (t >= 64 && t < 64 + MAX_SLOTS) hd->max_key[t - 64] = 0u;       // (after the first wave has read the maximum)
+    unsigned off = 0;
+    for (int q = 0; q < wv; ++q) off += s_w[q];
+    if (t == NT - 1) { *s_n = off + inc; hd->n_cand = off + inc; }
+    __syncthreads();
+    const unsigned n = *s_n;
+    unsigned e0 = off + inc - mine;
+    unsigned first = e0;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { const unsigned k = cnt[i]; cnt[i] = e0; e0 += k; }     // cnt[i] := start of bucket i
+#pragma unroll
+    for (int i = 0; i < BPT / 4; ++i)
+        reinterpret_cast<uint4*>(cursor_img)[t * (BPT / 4) + i] = make_uint4(cnt[4 * i], cnt[4 * i + 1], cnt[4 * i + 2], cnt[4 * i + 3]);
+    for (int k = 0; k < N_SEG; ++k) {
+        unsigned long long want = base ? ((unsigned long long)base << k) : (unsigned long long)n;
+        // a prefix that is already a sizeable part of the list is not worth a possible second pass
+        if (k == N_SEG - 1 || want > n || (unsigned long long)n <= (unsigned long long)full_ratio * base) want = n;
+        const unsigned tk = (unsigned)want;
+        if (tk == 0) { if (t == 0) hd->seg_end[k] = 0; continue; }
+        if (!(first < tk && e0 >= tk)) continue;              // the boundary bucket is not among this thread's
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const unsigned end_i = (i + 1 < BPT) ? cnt[i + 1] : e0;
+            if (cnt[i] < tk && end_i >= tk) hd->seg_end[k] = end_i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bucket_scan(unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
+                                                    GfttHdr* __restrict__ hdr, unsigned base, unsigned full_ratio, double quality) {
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_n;
+    bucket_scan_body<1024>(hist + (size_t)blockIdx.x * N_BUCKET, cursor + (size_t)blockIdx.x * N_BUCKET, hdr + blockIdx.x,
+                           base, full_ratio, quality, s_w, &s_n);
+}
+
 __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, int h, int w, double quality,
-                                               const GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
+                                               GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
                                                unsigned* __restrict__ ckey, unsigned* __restrict__ hist,
                                                const uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -356,103 +434,38 @@ __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, 
     const float thr = gftt_threshold(mk, quality);
     const BucketMap bm = bucket_map(mk, thr);
     unsigned* hs = hist + ((size_t)blockIdx.z * N_COPY + tile_copy(blockIdx.x * 64, blockIdx.y * (4 * NMS_ROWS))) * N_BUCKET;
-    if (x >= w) return;
+    if (x < w) {
 #pragma unroll
-    for (int k = 0; k < NMS_ROWS; ++k) {
-        const int y = y0 + 4 * k;
-        if (y >= h) break;
-        bool is = false;
-        float v = 0.f;
-        if (mk && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-            const float* p = sc + (size_t)y * w + x;
-            v = p[0];
-            if (v > thr && v != 0.f && (!mask || mask[(size_t)y * w + x])) {
-                float m = fmaxf(fmaxf(p[-w - 1], p[-w]), p[-w + 1]);
-                m = fmaxf(m, fmaxf(p[-1], p[1]));
-                m = fmaxf(m, fmaxf(fmaxf(p[w - 1], p[w]), p[w + 1]));
-                is = v >= m;
+        for (int k = 0; k < NMS_ROWS; ++k) {
+            const int y = y0 + 4 * k;
+            if (y >= h) break;
+            bool is = false;
+            float v = 0.f;
+            if (mk && x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+                const float* p = sc + (size_t)y * w + x;
+                v = p[0];
+                if (v > thr && v != 0.f && (!mask || mask[(size_t)y * w + x])) {
+                    float m = fmaxf(fmaxf(p[-w - 1], p[-w]), p[-w + 1]);
+                    m = fmaxf(m, fmaxf(p[-1], p[1]));
+                    m = fmaxf(m, fmaxf(fmaxf(p[w - 1], p[w]), p[w + 1]));
+                    is = v >= m;
+                }
             }
+            const unsigned d = is ? bucket_of(bm, __float_as_uint(v)) : 0u;
+            state[ib + (size_t)y * w + x] = is ? (uint16_t)((d << 2) | 1u) : (uint16_t)0;
+            ckey[ib + (size_t)y * w + x] = is ? __float_as_uint(v) : 0u;
+            if (is) atomicAdd(&hs[d], 1u);
         }
-        const unsigned d = is ? bucket_of(bm, __float_as_uint(v)) : 0u;
-        state[ib + (size_t)y * w + x] = is ? (uint16_t)((d << 2) | 1u) : (uint16_t)0;
-        ckey[ib + (size_t)y * w + x] = is ? __float_as_uint(v) : 0u;
-        if (is) atomicAdd(&hs[d], 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// exclusive scan of the bucket histogram in (bucket, copy) order: one 1024-thread block per image,
-// N_BUCKET/1024 consecutive buckets per thread -> scatter cursors, the candidate count, and the
-// prefix lengths seg_end[k] = first bucket boundary >= min(n, base << k) (base = 0: everything).
-__global__ __launch_bounds__(1024) void bucket_scan(unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
-                                                    GfttHdr* __restrict__ hdr, unsigned base, unsigned full_ratio) {
-    __shared__ unsigned s_w[16];
-    __shared__ unsigned s_n;
-    const unsigned* hs = hist + (size_t)blockIdx.x * N_COPY * N_BUCKET;
-    unsigned* cs = cursor + (size_t)blockIdx.x * N_COPY * N_BUCKET;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    constexpr int BPT = N_BUCKET / 1024;                 // consecutive buckets per thread
-    static_assert(BPT % 4 == 0, "uint4 access");
-    unsigned cnt[BPT][N_COPY];
-    unsigned mine = 0;
-#pragma unroll
-    for (int c = 0; c < N_COPY; ++c)
-#pragma unroll
-        for (int i = 0; i < BPT / 4; ++i) {
-            const uint4 v = reinterpret_cast<const uint4*>(hs + (size_t)c * N_BUCKET)[t * (BPT / 4) + i];
-            cnt[4 * i][c] = v.x; cnt[4 * i + 1][c] = v.y; cnt[4 * i + 2][c] = v.z; cnt[4 * i + 3][c] = v.w;
-            mine += v.x + v.y + v.z + v.w;
-            // the histogram has been consumed: leave it zero for the next call (no memset command per call)
-            reinterpret_cast<uint4*>(hist + ((size_t)blockIdx.x * N_COPY + c) * N_BUCKET)[t * (BPT / 4) + i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    // likewise the header fields the next call expects to be zero; max_key was last read by nms_map, the accepted
-    // count and the round flags are first touched by the selection that follows this kernel
-    if (t < SELECT_ROUNDS) hdr[blockIdx.x].undecided[t] = 0u;
-    if (t == SELECT_ROUNDS) hdr[blockIdx.x].n_acc = 0u;
-    if (t >= 64 && t < 64 + MAX_SLOTS) hdr[blockIdx.x].max_key[t - 64] = 0u;
-    unsigned inc = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = (unsigned)__shfl_up((int)inc, o);
-        if (lane >= o) inc += u;
-    }
-    if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
-    unsigned off = 0;
-    for (int q = 0; q < wv; ++q) off += s_w[q];
-    if (t == 1023) { s_n = off + inc; hdr[blockIdx.x].n_cand = off + inc; }
-    __syncthreads();
-    const unsigned n = s_n;
-    unsigned e0 = off + inc - mine;
-    unsigned bstart[BPT + 1];
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-        bstart[i] = e0;
-#pragma unroll
-        for (int c = 0; c < N_COPY; ++c) { const unsigned k = cnt[i][c]; cnt[i][c] = e0; e0 += k; }
-    }
-    bstart[BPT] = e0;
-#pragma unroll
-    for (int c = 0; c < N_COPY; ++c)
-#pragma unroll
-        for (int i = 0; i < BPT / 4; ++i)
-            reinterpret_cast<uint4*>(cs + (size_t)c * N_BUCKET)[t * (BPT / 4) + i] =
-                make_uint4(cnt[4 * i][c], cnt[4 * i + 1][c], cnt[4 * i + 2][c], cnt[4 * i + 3][c]);
-    for (int k = 0; k < N_SEG; ++k) {
-        unsigned long long want = base ? ((unsigned long long)base << k) : (unsigned long long)n;
-        // a prefix that is already a sizeable part of the list is not worth a possible second pass
-        if (k == N_SEG - 1 || want > n || (unsigned long long)n <= (unsigned long long)full_ratio * base) want = n;
-        const unsigned tk = (unsigned)want;
-        if (tk == 0) { if (t == 0) hdr[blockIdx.x].seg_end[k] = 0; continue; }
-        if (!(bstart[0] < tk && e0 >= tk)) continue;          // the boundary bucket is not among this thread's
-#pragma unroll
-        for (int i = 0; i < BPT; ++i)
-            if (bstart[i] < tk && bstart[i + 1] >= tk) hdr[blockIdx.x].seg_end[k] = bstart[i + 1];
     }
 }
 
 // bucket-ordered candidate list, straight from the state map (8 pixels per thread)
-__global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict__ state, int h, int w,
-                                                      unsigned* __restrict__ cursor, unsigned* __restrict__ sorted) {
+// Beside the pixel index the list carries, by list position, the candidate's score bits (lkey) and an "accepted" flag
+// (lflag, cleared here, set by the selection), so that the last stage reads three contiguous arrays instead of chasing
+// list -> state map -> key map.
+__global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict__ state, const unsigned* __restrict__ ckey, int h, int w,
+                                                      unsigned* __restrict__ cursor, unsigned* __restrict__ sorted,
+                                                      unsigned* __restrict__ lkey, uint8_t* __restrict__ lflag) {
     const size_t px = (size_t)h * w;
     const uint16_t* stt = state + (size_t)blockIdx.y * px;
     unsigned* cs = cursor + (size_t)blockIdx.y * N_COPY * N_BUCKET;
@@ -478,6 +491,8 @@ __global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict
             const int y = (int)(p / (unsigned)w), x = (int)(p - (unsigned)y * w);
             const unsigned pos = atomicAdd(&cs[(size_t)tile_copy(x, y) * N_BUCKET + (v[i] >> 2)], 1u);
             sorted[(size_t)blockIdx.y * px + pos] = p;
+            lkey[(size_t)blockIdx.y * px + pos] = ckey[(size_t)blockIdx.y * px + p];
+            lflag[(size_t)blockIdx.y * px + pos] = 0;
         }
     }
 }
@@ -529,7 +544,7 @@ __device__ __forceinline__ void sel_fetch(const SelGeom& g, const uint16_t* stt,
 
 // decide one candidate from its (possibly slightly old) window; blocking neighbours are re-read.
 // Returns true when the candidate is still undecided.
-__device__ __forceinline__ bool sel_eval(const unsigned* __restrict__ ck, uint16_t* stt, const SelWin& W, int lane, int spins) {
+__device__ __forceinline__ bool sel_eval(const unsigned* __restrict__ ck, uint16_t* stt, const SelWin& W, int lane, int spins, uint8_t* lf) {
     if ((W.myv & 3u) != 1u) return false;
     const unsigned dp = W.myv >> 2, p = W.p;
     bool rel[SEL_CH];
@@ -555,12 +570,12 @@ __device__ __forceinline__ bool sel_eval(const unsigned* __restrict__ ck, uint16
         any_rej = __any(rej); any_blk = __any(blk);
     }
     if (any_rej) { if (lane == 0) st_state(stt + p, (dp << 2) | 3u); return false; }
-    if (!any_blk) { if (lane == 0) st_state(stt + p, (dp << 2) | 2u); return false; }
+    if (!any_blk) { if (lane == 0) { st_state(stt + p, (dp << 2) | 2u); *lf = 1; } return false; }
     return true;
 }
 
 // windows too large for registers: plain scan
-__device__ __forceinline__ bool sel_visit_large(const SelGeom& g, const unsigned* __restrict__ ck, uint16_t* stt, unsigned p, int lane) {
+__device__ __forceinline__ bool sel_visit_large(const SelGeom& g, const unsigned* __restrict__ ck, uint16_t* stt, unsigned p, int lane, uint8_t* lf) {
     const unsigned myv = ld_state(stt + p);
     if ((myv & 3u) != 1u) return false;
     const unsigned dp = myv >> 2;
@@ -577,7 +592,7 @@ __device__ __forceinline__ bool sel_visit_large(const SelGeom& g, const unsigned
         if (st == 2u) rej = true; else blk = true;
     }
     if (__any(rej)) { if (lane == 0) st_state(stt + p, (dp << 2) | 3u); return false; }
-    if (!__any(blk)) { if (lane == 0) st_state(stt + p, (dp << 2) | 2u); return false; }
+    if (!__any(blk)) { if (lane == 0) { st_state(stt + p, (dp << 2) | 2u); *lf = 1; } return false; }
     return true;
 }
 
@@ -586,11 +601,13 @@ __device__ __forceinline__ bool sel_visit_large(const SelGeom& g, const unsigned
 // to passes-1 sweeps over the ones still blocked (bit mask).
 __global__ __launch_bounds__(256) void select_round(const unsigned* __restrict__ ckey, int h, int w, int r, float md2,
                                                     GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
-                                                    const unsigned* __restrict__ cand, int seg, int passes, int spins, int slot) {
+                                                    const unsigned* __restrict__ cand, uint8_t* __restrict__ lflag, int seg, int passes,
+                                                    int spins, int slot) {
     if (slot > 0 && !hdr[blockIdx.y].undecided[slot - 1]) return;     // the previous launch settled everything
     const size_t ib = (size_t)blockIdx.y * h * w;
     const unsigned* ck = ckey + ib;
     const unsigned* cl = cand + ib;
+    uint8_t* lf = lflag + ib;
     uint16_t* stt = state + ib;
     const unsigned n = hdr[blockIdx.y].seg_end[seg];
     const int lane = threadIdx.x & 63;
@@ -611,12 +628,12 @@ __global__ __launch_bounds__(256) void select_round(const unsigned* __restrict__
                 const unsigned p1 = p_next;
                 if (k + 2 < kmax) p_next = cl[c0 + (k + 2) * nwaves];
                 if (k + 1 < kmax) sel_fetch(g, stt, p1, lane, nxt);
-                if (sel_eval(ck, stt, cur, lane, spins)) pending |= 1ull << k;
+                if (sel_eval(ck, stt, cur, lane, spins, lf + c0 + k * nwaves)) pending |= 1ull << k;
                 cur = nxt;
             }
         } else {
             for (unsigned k = 0; k < kmax; ++k)
-                if (sel_visit_large(g, ck, stt, cl[c0 + k * nwaves], lane)) pending |= 1ull << k;
+                if (sel_visit_large(g, ck, stt, cl[c0 + k * nwaves], lane, lf + c0 + k * nwaves)) pending |= 1ull << k;
         }
         for (int pass = 1; pass < passes && pending; ++pass) {
             unsigned long long m = pending;
@@ -625,8 +642,8 @@ __global__ __launch_bounds__(256) void select_round(const unsigned* __restrict__
                 m &= m - 1;
                 const unsigned p = cl[c0 + k * nwaves];
                 bool l;
-                if (small) { SelWin W; sel_fetch(g, stt, p, lane, W); l = sel_eval(ck, stt, W, lane, spins); }
-                else l = sel_visit_large(g, ck, stt, p, lane);
+                if (small) { SelWin W; sel_fetch(g, stt, p, lane, W); l = sel_eval(ck, stt, W, lane, spins, lf + c0 + k * nwaves); }
+                else l = sel_visit_large(g, ck, stt, p, lane, lf + c0 + k * nwaves);
                 if (!l) pending &= ~(1ull << k);
             }
         }
@@ -799,6 +816,110 @@ __global__ __launch_bounds__(256) void emit_ranked(const unsigned long long* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Last stage of a detector call when the rank prefix is short (the reference's settings: a few thousand candidates):
+// ONE block per image replaces gather_accepted + rank_count + emit_ranked.  The candidate list is in bucket order
+// (coarse rank), so an order-preserving compaction of the accepted candidates is already sorted except inside runs of
+// equal bucket; rank = run start + number of larger keys in the run (keys are unique), exact whatever the run length.
+// Thread t owns the candidates [t*m, (t+1)*m) of the prefix; block-wide exclusive scan of the accepted counts; keys and
+// buckets of the accepted candidates go to LDS in list order; then the run fix-up and the scatter of (x, y) to rank
+// order, into the caller's buffer and (host_corners) into mapped pinned host memory, followed by the header.
+constexpr unsigned FIN_MAX = 12288;              // prefix length one block handles (keys 96 KiB + buckets 24 KiB of LDS)
+constexpr int FIN_PER = FIN_MAX / 1024;
+__global__ __launch_bounds__(1024) void finish_small(int h, int w, GfttHdr* __restrict__ hdr, const unsigned* __restrict__ cand,
+                                                     const unsigned* __restrict__ lkey, const uint8_t* __restrict__ lflag,
+                                                     int take_all, int seg, float* __restrict__ corners, int out_stride,
+                                                     int max_out, GfttHdr* __restrict__ host_hdr, float* __restrict__ host_corners) {
+    extern __shared__ unsigned long long fin_keys[];
+    uint16_t* fin_bkt = reinterpret_cast<uint16_t*>(fin_keys + FIN_MAX);
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_tot;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int img = blockIdx.x;
+    const size_t ib = (size_t)img * h * w;
+    GfttHdr* hd = hdr + img;
+    const unsigned n = hd->seg_end[seg];
+    if (n > FIN_MAX) {                                // uniform: too long for one block, the host runs the split chain
+        if (t == 0) hd->fin_state = 2u;
+        __syncthreads();
+        if (host_hdr && t < sizeof(GfttHdr) / 4) reinterpret_cast<unsigned*>(host_hdr + img)[t] = reinterpret_cast<const unsigned*>(hd)[t];
+        return;
+    }
+    const unsigned m = (n + 1023u) / 1024u;           // candidates per thread (<= FIN_PER)
+    const unsigned c0 = (unsigned)t * m;
+    BucketMap bm;
+    bm.mb = hd->bm_mb; bm.shift = hd->bm_shift;
+    unsigned p[FIN_PER], kb[FIN_PER];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_PER; ++i) {                // three contiguous, independent reads per candidate
+        const unsigned c = c0 + i;
+        const bool in = (unsigned)i < m && c < n;
+        p[i] = in ? cand[ib + c] : 0xffffffffu;
+        kb[i] = in ? lkey[ib + c] : 0u;
+        const unsigned fl = (in && !take_all) ? (unsigned)lflag[ib + c] : 1u;
+        if (!(in && fl)) p[i] = 0xffffffffu;
+        cnt += p[i] != 0xffffffffu ? 1u : 0u;
+    }
+    unsigned inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    unsigned off = 0;
+    for (int q = 0; q < wv; ++q) off += s_w[q];
+    if (t == 1023) s_tot = off + inc;
+    unsigned pos = off + inc - cnt;
+#pragma unroll
+    for (int i = 0; i < FIN_PER; ++i)
+        if (p[i] != 0xffffffffu) {
+            fin_keys[pos] = ((unsigned long long)kb[i] << 32) | p[i];
+            fin_bkt[pos] = (uint16_t)bucket_of(bm, kb[i]);
+            ++pos;
+        }
+    __syncthreads();
+    const unsigned na = s_tot;
+    float2* out = reinterpret_cast<float2*>(corners) + (size_t)img * out_stride;
+    // ranks first (registers), then the (x, y) pairs go through LDS in rank order, so that the stores to the caller's buffer
+    // and to mapped host memory are contiguous (2 000 scattered 8-byte writes over the bus cost ~6 us)
+    unsigned rks[FIN_PER];
+    float2 cs[FIN_PER];
+#pragma unroll
+    for (int i = 0; i < FIN_PER; ++i) {
+        const unsigned j = (unsigned)t + 1024u * i;
+        rks[i] = 0xffffffffu;
+        cs[i] = make_float2(0.f, 0.f);
+        if (j >= na) continue;
+        const unsigned d = fin_bkt[j];
+        const unsigned long long key = fin_keys[j];
+        unsigned lo = j, hi = j + 1;
+        while (lo > 0 && fin_bkt[lo - 1] == d) --lo;
+        while (hi < na && fin_bkt[hi] == d) ++hi;
+        unsigned rk = lo;
+        for (unsigned k = lo; k < hi; ++k) rk += fin_keys[k] > key ? 1u : 0u;
+        const unsigned q = (unsigned)(key & 0xffffffffull);
+        const unsigned y = q / (unsigned)w;
+        rks[i] = rk;
+        cs[i] = make_float2((float)(q - y * w), (float)y);
+    }
+    __syncthreads();                                  // every key has been read: the key array becomes the output stage
+    float2* stage = reinterpret_cast<float2*>(fin_keys);
+#pragma unroll
+    for (int i = 0; i < FIN_PER; ++i) if (rks[i] != 0xffffffffu) stage[rks[i]] = cs[i];
+    __syncthreads();
+    const unsigned nout = min(na, (unsigned)max(max_out, 0));
+    for (unsigned j = t; j < nout; j += 1024) {
+        const float2 c = stage[j];
+        out[j] = c;
+        if (host_corners) reinterpret_cast<float2*>(host_corners)[j] = c;
+    }
+    if (t == 0) { hd->n_acc = na; hd->fin_state = 1u; }
+    __syncthreads();
+    if (host_hdr && t < sizeof(GfttHdr) / 4) reinterpret_cast<unsigned*>(host_hdr + img)[t] = reinterpret_cast<const unsigned*>(hd)[t];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -811,7 +932,7 @@ constexpr size_t NOALLOC_MAX_PX = VOFE_NOALLOC_MAX_PIXELS;
 constexpr size_t NOALLOC_HDR_BYTES = 256;
 static_assert(sizeof(GfttHdr) <= NOALLOC_HDR_BYTES, "one header");
 constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_HDR_BYTES + 2 * (size_t)N_COPY * N_BUCKET * sizeof(unsigned) +
-                                         NOALLOC_MAX_PX * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
+                                         NOALLOC_MAX_PX * GFTT_BYTES_PER_PX + 1024 + 32;
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 constexpr int VOFE_MAX_DEVICES = 64;
@@ -910,10 +1031,11 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
-    // workspace: hdr | bucket histograms | bucket cursors | keys u64 | score f32 | bucket-ordered candidates u32 (ranks after the gather) | ckey u32 | state u16
+    // workspace: hdr | bucket histograms | bucket cursors | keys u64 | score f32 (ranks after the gather) | bucket-ordered
+    // candidates u32 | ckey u32 | lkey u32 (score bits by list position) | state u16 | lflag u8 (accepted, by list position)
     const size_t hdr_bytes = ((sizeof(GfttHdr) * batch + 255) / 256) * 256;
     const size_t hist_bytes = (size_t)batch * N_COPY * N_BUCKET * sizeof(unsigned);
-    const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * (8 + 4 + 4 + 4 + 2) + 1024 + 16;
+    const size_t tot = hdr_bytes + 2 * hist_bytes + batch * px * GFTT_BYTES_PER_PX + 1024 + 16;
     int rc = VOFE_OK;
     uint8_t* base = nullptr;
     if (noalloc) {
@@ -952,7 +1074,9 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     float* score = reinterpret_cast<float*>(maps + batch * px * 8);
     unsigned* cand = reinterpret_cast<unsigned*>(maps + batch * px * 12);
     unsigned* ckey = reinterpret_cast<unsigned*>(maps + batch * px * 16);
-    uint16_t* state = reinterpret_cast<uint16_t*>(maps + ((batch * px * 20 + 15) & ~(size_t)15));   // 16-byte aligned
+    unsigned* lkey = reinterpret_cast<unsigned*>(maps + batch * px * 20);
+    uint16_t* state = reinterpret_cast<uint16_t*>(maps + ((batch * px * 24 + 15) & ~(size_t)15));   // 16-byte aligned
+    uint8_t* lflag = reinterpret_cast<uint8_t*>(state) + batch * px * 2;
 
     const bool suppress = min_distance >= 1.0;
     // schedule of the selection (measured, profiles/r01_host_paths.txt; any values give the same corners, see
@@ -997,14 +1121,16 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
                                   reinterpret_cast<unsigned*>(hdr), d_mask);
     if (rc) return rc;
+    // VOFE_GFTT_CHAIN=split keeps the longer chain of round 1 (tests: both chains must give the same corners)
+    const bool merged = kn.gftt_chain != 's';     // VOFE_GFTT_CHAIN=split: the last stage as three launches (tests: same corners)
     { VOFE_TIMED(ctx, "nms_map");
     hipLaunchKernelGGL(nms_map, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
                        score, h, w, quality, hdr, state, ckey, hist, d_mask); }
     { VOFE_TIMED(ctx, "bucket_scan");
-    hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full); }
+    hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full, quality); }
     { VOFE_TIMED(ctx, "bucket_scatter");
     hipLaunchKernelGGL(bucket_scatter, dim3((unsigned)std::min<size_t>((px + 2047) / 2048, 2048), batch), dim3(256), 0, st,
-                       state, h, w, cursor, cand); }
+                       state, ckey, h, w, cursor, cand, lkey, lflag); }
     int r = 0;
     float md2 = 0.f;
     if (suppress) {
@@ -1032,8 +1158,34 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             for (int round = 0; round < sel_launches; ++round) {
                 VOFE_TIMED(ctx, "select_round");
                 hipLaunchKernelGGL(select_round, dim3(sel_blocks, batch), dim3(256), 0, st, ckey, h, w, r, md2, hdr, state,
-                                   cand, seg, sel_passes, sel_spins, round);
+                                   cand, lflag, seg, sel_passes, sel_spins, round);
             }
+        // Last stage.  A short rank prefix (the reference's settings) is finished by ONE block per image; its length is
+        // known on the device only, so the host goes by the prefix it asked for (or, for the whole list, by the candidate
+        // count of this context's previous call: consecutive frames of a camera are alike), and the kernel reports
+        // back when the prefix was longer than one block handles (fin_state 2: the split chain runs after all).
+        const unsigned long long last = ctx->gftt_last_ncand;
+        // (bucket_scan takes the whole list when it is at most sel_full prefixes long, or when no prefix was asked for)
+        const bool whole = !seg_base || seg >= N_SEG - 1 || (last && last <= (unsigned long long)sel_full * seg_base);
+        unsigned long long ub_fin = whole ? (last ? last : px) : ((unsigned long long)seg_base << seg);
+        if (!whole && last) ub_fin = std::min(ub_fin, last);
+        const bool fin = merged && use_rank && max_out > 0 && ub_fin + ub_fin / 4 <= FIN_MAX;
+        bool split = !fin;
+        if (fin) {
+            static bool lds_set = false;
+            const size_t fin_lds = (size_t)FIN_MAX * (8 + 2);
+            if (!lds_set) {
+                VOFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(finish_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+                lds_set = true;
+            }
+            { VOFE_TIMED(ctx, "finish_small");
+            hipLaunchKernelGGL(finish_small, dim3(batch), dim3(1024), fin_lds, st, h, w, hdr, cand, lkey, lflag, suppress ? 0 : 1, seg,
+                               d_corners_xy, capacity, max_out, reinterpret_cast<GfttHdr*>(ctx->d_pinned),
+                               stage_floats ? reinterpret_cast<float*>(ctx->d_pinned + hdr_ints) : nullptr); }
+            VOFE_HIP(hipStreamSynchronize(st));
+            for (int b = 0; b < batch; ++b) split = split || hh[b].fin_state == 2u;
+        }
+        if (split) {
         { VOFE_TIMED(ctx, "gather_accepted");
         hipLaunchKernelGGL(gather_accepted, dim3(256, batch), dim3(256), 0, st, ckey, h, w, hdr, state, cand, keys,
                            rank, suppress ? 0 : 1, seg); }
@@ -1054,6 +1206,10 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             VOFE_HIP(hipMemcpyAsync(hh, hdr, sizeof(GfttHdr) * batch, hipMemcpyDeviceToHost, st));
         }
         VOFE_HIP(hipStreamSynchronize(st));
+        }
+        unsigned ncand_max = 0;
+        for (int b = 0; b < batch; ++b) ncand_max = std::max(ncand_max, hh[b].n_cand);
+        ctx->gftt_last_ncand = ncand_max;
         bool converged = true, enough = true;
         for (int b = 0; b < batch; ++b) {
             if (suppress && hh[b].undecided[sel_launches - 1]) converged = false;

@@ -32,7 +32,7 @@ struct VofeKnobs {
     int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
     bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
     bool gftt_debug;          // VOFE_GFTT_DEBUG
-    bool gftt_chain;          // VOFE_GFTT_CHAIN=split: the unmerged detector launch chain
+    char gftt_chain;          // VOFE_GFTT_CHAIN: 's'plit = the detector's last stage as three launches (round 1's chain)
     int sel_blocks, sel_launches, sel_passes, sel_spins, sel_prefix, sel_full;   // VOFE_SEL_*
 };
 
@@ -54,6 +54,7 @@ struct vofe_ctx {
     size_t h_pinned_ints;
     int gftt_clean_batch;     // batch count whose header/histogram layout the last detector call left zeroed (0: none)
     void* gftt_clean_ws;      // ... in this workspace allocation
+    unsigned gftt_last_ncand; // candidates of the previous detector call (sizes the last stage when the whole list is taken)
     unsigned long long* lk_counters;   // optional device counters (vofe_lk_set_counters)
 };
 
