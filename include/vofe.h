@@ -179,6 +179,10 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
  * raises on the empty reduction; the Python mirror keeps that).  Asynchronous on the ctx stream. */
 int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
                           const float* d_existing_xy, int n_existing, double threshold, uint8_t* d_mask);
+/* The same with the existing points in two arrays (reference continuous.py:408: np.vstack([Ci.T, Pi.T]) -- the
+ * candidates and the landmarks live in separate device buffers, the stacked copy is never made). */
+int vofe_new_feature_mask2(vofe_ctx* ctx, const float* d_features_xy, int n_features, const float* d_existing_a_xy, int n_a,
+                           const float* d_existing_b_xy, int n_b, double threshold, uint8_t* d_mask);
 
 /* Replaces the candidate update of reference continuous.py:391-405 and the triangulation test of :446-448:
  *     valid = status == 1;  Ci = tracked[:, valid];  Fi = Fi[:, valid];  Ti = Ti[:, valid]
@@ -210,6 +214,24 @@ int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* 
                                 const void* d_first_xy, int first_is_f64, const double* d_transform,
                                 int transform_dim, const uint8_t* d_flag_in, int n, double alpha_min,
                                 uint8_t* d_flag_out, double* d_xyz);
+
+/* Replaces the tail of ContinuousVO._handle_candidates (reference continuous.py:476-495) on device-resident arrays:
+ *     Pi = hstack([Pi, Ci[:, new_landmarks]]);  Xi = hstack([Xi, points3D])              -> promoted candidates
+ *     Ci, Fi, Ti = Ci[:, no_new_landmark], ...                                           -> removed from the candidates, in order
+ *     Ci = hstack([Ci, new_features]); Fi = hstack([Fi, new_features]); Ti = hstack([Ti, tiled_pose])
+ * d_cand_xy / d_first_xy / d_transform hold n_candidates candidates (capacity cap_candidates) as vofe_candidate_filter
+ * left them and are updated in place; d_promote (n_candidates) is the flag array of vofe_triangulate_candidates and
+ * d_xyz its points; d_features_xy / d_feature_mask (n_features) are the detections of the frame and the mask of
+ * vofe_new_feature_mask; d_pose the current 3x4 pose.  Promoted candidates are appended to d_landmarks_xy (n_landmarks
+ * entries, capacity cap_landmarks) and written with their 3-D points to d_new_landmarks_xy / _xyz (which may be pinned
+ * host memory mapped into the device, so the host appends them to its own Pi / Xi).  d_track_next receives the next
+ * frame's tracking input [landmarks | candidates] and d_counts = {promoted, candidates, landmarks, overflow flag}.
+ * Order-preserving throughout, as numpy's boolean indexing is.  Asynchronous on the ctx stream. */
+int vofe_candidate_commit(vofe_ctx* ctx, float* d_cand_xy, void* d_first_xy, int first_is_f64, double* d_transform,
+                          int transform_dim, int n_candidates, int cap_candidates, const uint8_t* d_promote, const double* d_xyz,
+                          const float* d_features_xy, const uint8_t* d_feature_mask, int n_features, const double* d_pose,
+                          float* d_landmarks_xy, int n_landmarks, int cap_landmarks, float* d_track_next, float* d_new_landmarks_xy,
+                          double* d_new_landmarks_xyz, int* d_counts);
 
 #ifdef __cplusplus
 }

@@ -954,6 +954,60 @@ def test_handle_candidates_follows_the_reference_method_over_a_sequence(fe):
     assert promoted > 0 and grown == 6 and Ci.shape[1] > 100
 
 
+def test_device_resident_frame_state_follows_the_reference_frame_loop(fe):
+    """DeviceFrameState (landmarks and candidates resident in HBM, two device phases per frame around the CPU pose
+    estimation) against the reference's per-frame sequence restated with the oracle: landmark tracking
+    (continuous.py:86-92), a stand-in for the pose estimation's inlier selection, _handle_candidates (:375-495).  Every
+    frame both sides start from their OWN previous state, so differences would accumulate; all arrays must stay equal."""
+    from visual_odometry_amd import DeviceFrameState
+    H, W = 376, 1241
+    frames = _seq(H, W, 3, 7)
+    K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.2], [0, 0, 1.0]])
+
+    def pose_at(t):
+        T = np.eye(4)
+        T[:3, 3] = [0.02 * t, 0.0, 0.6 * t]
+        return T
+
+    first = oracle.goodFeaturesToTrack(frames[0], 900, 0.01, 10).reshape(-1, 2)
+    rng = np.random.default_rng(4)
+    Pi = first[::3].T.copy()                                     # a third of the detections start as landmarks
+    Xi = rng.normal(0, 5, (3, Pi.shape[1])) + [[0], [0], [20]]
+    cand = np.delete(first, np.arange(0, first.shape[0], 3), axis=0)
+    Ci = cand.T.copy()
+    Fi = cand.T.astype(np.float64)
+    Ti = np.tile(pose_at(0)[:3, :].reshape(-1, 1), (1, Ci.shape[1]))
+    kw = dict(max_corners=600, quality_level=0.01, min_distance=10, threshold_alpha_deg=0.05)
+    st = DeviceFrameState(H, W, K, frontend=fe, **kw)
+    st.reset(frames[0], Pi, Xi, Ci, Fi, Ti)
+    for name, g, r in zip(("Pi", "Xi", "Ci", "Fi", "Ti"), st.download(), (Pi, Xi, Ci, Fi, Ti)):
+        assert g.shape == r.shape and np.array_equal(g, r), name
+    promoted = 0
+    for t in range(1, 7):
+        pose = pose_at(t)
+        # reference side (oracle for the cv2 calls)
+        rt, rs, _ = oracle.track_keypoints(Pi, frames[t - 1], frames[t], nthreads=8)
+        gt, gs = st.track(frames[t])
+        assert gt.dtype == np.float32 and np.array_equal(gt, rt) and np.array_equal(gs, rs), t
+        keep = rs == 1
+        keep[::7] = False                                        # stand-in for the RANSAC inlier mask (continuous.py:95-101)
+        Pi, Xi = rt[:, keep], Xi[:, keep]
+        with np.errstate(all="ignore"):
+            rPi, rXi, Ci, Fi, Ti = oracle.handle_candidates(K, frames[t], frames[t - 1], Ci, Fi, Ti, Pi, Xi, pose, **kw)
+        promoted += st.update(pose, keep)
+        gPi, gXi, gCi, gFi, gTi = st.download()
+        for name, g, r in (("Pi", gPi, rPi), ("Ci", gCi, Ci), ("Fi", gFi, Fi), ("Ti", gTi, Ti)):
+            assert g.shape == r.shape and np.array_equal(g, r), (t, name, g.shape, r.shape)
+        assert gPi.dtype == np.float32 and gFi.dtype == np.float64
+        assert gXi.shape == rXi.shape and np.allclose(gXi, rXi, rtol=1e-6, atol=1e-6), t
+        Pi, Xi = rPi, rXi
+    assert promoted > 0
+    assert Ci.shape[1] > 100 and Pi.shape[1] > 100
+    with pytest.raises(Exception):
+        st.update(pose_at(7), np.ones(st.K, bool))               # update() without track()
+    st.close()
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -120,8 +120,73 @@ def sequences_64(fe, reps):
             "gftt_us_per_image": round(tg * 1e6 / B, 2), "tracked_fraction": round(float(ds.float().mean()), 4)}
 
 
+def frame_loop(fe, cfg, md, n_land, n_cand, max_corners, n_frames=8, rounds=6):
+    """The reference's whole per-frame front end, host to host (numpy frame in; tracked landmarks out for the CPU pose
+    estimation; pose + inlier mask in; updated state): landmark tracking + _handle_candidates (continuous.py:86-92,
+    375-495).  (a) per-call path: SequenceTracker.track for the landmarks, FrontEnd.handle_candidates for the rest (every
+    stage on the device, arrays through the host between stages); (b) DeviceFrameState: arrays resident, two device phases."""
+    from visual_odometry_amd import DeviceFrameState
+    H, W, seed, _, win, lvl = synthetic.CONFIGS[cfg]
+    fr = synthetic.sequence(H, W, seed, n_frames)
+    Kmat = np.array([[700.0, 0, W / 2], [0, 700.0, H / 2], [0, 0, 1.0]])
+
+    def pose_at(t):
+        T = np.eye(4)
+        T[:3, 3] = [0.02 * t, 0.0, 0.6 * t]
+        return T
+    first = fe.goodFeaturesToTrack(fr[0], n_land + n_cand, 0.01, md).reshape(-1, 2)
+    rng = np.random.default_rng(1)
+    P0 = first[:n_land].T.copy()
+    X0 = rng.normal(0, 5, (3, P0.shape[1])) + [[0], [0], [20]]
+    C0 = first[n_land:].T.copy()
+    F0 = C0.astype(np.float64)
+    T0 = np.tile(pose_at(0)[:3, :].reshape(-1, 1), (1, C0.shape[1]))
+    kw = dict(max_corners=max_corners, quality_level=0.01, min_distance=md)
+    lk = dict(winSize=win, maxLevel=lvl)
+    st = DeviceFrameState(H, W, Kmat, winSize=win, maxLevel=lvl, frontend=fe, **kw)
+    trk = SequenceTracker(H, W, winSize=win, maxLevel=lvl, frontend=fe)
+    t_dev = t_call = 0.0
+    sizes = None
+    for r in range(rounds + 1):
+        st.reset(fr[0], P0, X0, C0, F0, T0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(1, n_frames):
+            _, status = st.track(fr[t])
+            st.update(pose_at(t), status == 1)
+        dt = time.perf_counter() - t0
+        sizes = (st.K, st.M)
+        trk.reset(fr[0])
+        Pi, Xi, Ci, Fi, Ti = P0, X0, C0, F0, T0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(1, n_frames):
+            (tp, ts, _), = trk.track(fr[t], Pi)
+            keep = ts == 1
+            Pi, Xi, Ci, Fi, Ti = fe.handle_candidates(Kmat, fr[t], fr[t - 1], Ci, Fi, Ti, tp[:, keep], Xi[:, keep], pose_at(t),
+                                                     lk_params=lk, **kw)
+        dc = time.perf_counter() - t0
+        if r:                                     # the first round warms up
+            t_dev += dt
+            t_call += dc
+    st.close()
+    trk.close()
+    nfr = rounds * (n_frames - 1)
+    return {"config": cfg + " frame loop", "frame": "%dx%d, %d landmarks + %d candidates at the start, GFTT maxCorners %d minDistance %d, "
+            "win %dx%d" % (W, H, P0.shape[1], C0.shape[1], max_corners, md, win[0], win[1]),
+            "frame_us_device_resident_state": round(t_dev / nfr * 1e6, 1), "frame_us_per_call_path": round(t_call / nfr * 1e6, 1),
+            "landmarks_candidates_at_the_end": sizes, "frames_timed": nfr,
+            "note": "host to host: numpy frame in, landmark positions out, pose + mask in; pose estimation itself not included"}
+
+
 def main():
     fe = FrontEnd(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loop":
+        for r in (frame_loop(fe, "malaga", 10, 1000, 2000, 3000), frame_loop(fe, "malaga", 10, 300, 700, 1000),
+                  frame_loop(fe, "kitti", 10, 300, 700, 1000), frame_loop(fe, "parking", 10, 300, 700, 1000)):
+            print(json.dumps(r), flush=True)
+        fe.close()
+        return
     res = [front_end_frame(fe, "parking", 10, 100), front_end_frame(fe, "malaga", 10, 100), front_end_frame(fe, "stress", 10, 20),
            sequences_64(fe, 8)]
     fe.close()

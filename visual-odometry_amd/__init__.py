@@ -21,4 +21,7 @@ def __getattr__(name):
     if name in ("SequenceTracker", "MultiSequenceTracker"):
         from . import sequence
         return getattr(sequence, name)
+    if name == "DeviceFrameState":
+        from . import device_state
+        return device_state.DeviceFrameState
     raise AttributeError(name)

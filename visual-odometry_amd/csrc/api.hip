@@ -453,7 +453,19 @@ int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_featu
         return VOFE_E_ARG;
     }
     VOFE_BIND(ctx);
-    return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_xy, n_existing, threshold, d_mask);
+    return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_xy, n_existing, nullptr, 0, threshold, d_mask);
+}
+
+int vofe_new_feature_mask2(vofe_ctx* ctx, const float* d_features_xy, int n_features, const float* d_existing_a_xy, int n_a,
+                           const float* d_existing_b_xy, int n_b, double threshold, uint8_t* d_mask) {
+    if (!ctx) { vofe_set_error("vofe_new_feature_mask2: ctx is NULL"); return VOFE_E_ARG; }
+    if (n_features < 0 || n_a < 0 || n_b < 0) { vofe_set_error("vofe_new_feature_mask2: negative count"); return VOFE_E_ARG; }
+    if ((n_features > 0 && (!d_features_xy || !d_mask)) || (n_a > 0 && !d_existing_a_xy) || (n_b > 0 && !d_existing_b_xy)) {
+        vofe_set_error("vofe_new_feature_mask2: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    VOFE_BIND(ctx);
+    return vofe_launch_new_feature_mask(ctx, d_features_xy, n_features, d_existing_a_xy, n_a, d_existing_b_xy, n_b, threshold, d_mask);
 }
 
 int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status,
@@ -501,6 +513,29 @@ int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* 
     VOFE_BIND(ctx);
     return vofe_launch_triangulate(ctx, d_K, d_pose, d_cur_xy, d_first_xy, first_is_f64, d_transform, transform_dim, d_flag_in, n,
                                    alpha_min, d_flag_out, d_xyz);
+}
+
+int vofe_candidate_commit(vofe_ctx* ctx, float* d_cand_xy, void* d_first_xy, int first_is_f64, double* d_transform,
+                          int transform_dim, int n_candidates, int cap_candidates, const uint8_t* d_promote, const double* d_xyz,
+                          const float* d_features_xy, const uint8_t* d_feature_mask, int n_features, const double* d_pose,
+                          float* d_landmarks_xy, int n_landmarks, int cap_landmarks, float* d_track_next, float* d_new_landmarks_xy,
+                          double* d_new_landmarks_xyz, int* d_counts) {
+    if (!ctx) { vofe_set_error("vofe_candidate_commit: ctx is NULL"); return VOFE_E_ARG; }
+    if (n_candidates < 0 || n_features < 0 || n_landmarks < 0 || cap_candidates < n_candidates || cap_landmarks < n_landmarks) {
+        vofe_set_error("vofe_candidate_commit: counts must be >= 0 and within the capacities");
+        return VOFE_E_ARG;
+    }
+    if (transform_dim < 12 || transform_dim > 16) { vofe_set_error("vofe_candidate_commit: transform_dim must be 12..16, got %d", transform_dim); return VOFE_E_ARG; }
+    if (!d_counts || !d_pose || !d_track_next || (cap_candidates > 0 && (!d_cand_xy || !d_first_xy || !d_transform)) ||
+        (cap_landmarks > 0 && !d_landmarks_xy) || (n_candidates > 0 && (!d_promote || !d_xyz || !d_new_landmarks_xy || !d_new_landmarks_xyz)) ||
+        (n_features > 0 && (!d_features_xy || !d_feature_mask))) {
+        vofe_set_error("vofe_candidate_commit: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    VOFE_BIND(ctx);
+    return vofe_launch_candidate_commit(ctx, d_cand_xy, d_first_xy, first_is_f64, d_transform, transform_dim, n_candidates, cap_candidates,
+                                        d_promote, d_xyz, d_features_xy, d_feature_mask, n_features, d_pose, d_landmarks_xy, n_landmarks,
+                                        cap_landmarks, d_track_next, d_new_landmarks_xy, d_new_landmarks_xyz, d_counts);
 }
 
 }  // extern "C"

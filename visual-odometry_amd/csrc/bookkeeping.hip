@@ -22,6 +22,7 @@ namespace {
 // L2), then a butterfly minimum.  Small problems (1000 x 2000) would otherwise occupy a handful of CUs.
 __global__ __launch_bounds__(256) void new_feature_mask_kernel(const float2* __restrict__ feat, int nf,
                                                                const float2* __restrict__ exist, int ne,
+                                                               const float2* __restrict__ exist2, int ne2,
                                                                double s_star, uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -32,6 +33,13 @@ __global__ __launch_bounds__(256) void new_feature_mask_kernel(const float2* __r
     bool bad = false;
     for (int j = lane; j < ne; j += 64) {
         const float2 e = exist[j];
+        const double dx = fx - (double)e.x, dy = fy - (double)e.y;
+        const double s = dx * dx + dy * dy;
+        bad |= (s != s);
+        m = s < m ? s : m;
+    }
+    for (int j = lane; j < ne2; j += 64) {                   // second set (landmarks kept apart from the candidates)
+        const float2 e = exist2[j];
         const double dx = fx - (double)e.x, dy = fy - (double)e.y;
         const double s = dx * dx + dy * dy;
         bad |= (s != s);
@@ -217,6 +225,96 @@ __global__ __launch_bounds__(64) void triangulate_kernel(const double* __restric
     flag_out[i] = keep ? 1 : 0;
 }
 
+// ---- tail of _handle_candidates on the device (reference continuous.py:476-495) -------------------------------------
+//     Pi = np.hstack([Pi, Ci[:, new_landmarks]]);  Xi = np.hstack([Xi, points3D])          # promoted candidates
+//     Ci, Fi, Ti = Ci[:, no_new_landmark], Fi[:, no_new_landmark], Ti[:, no_new_landmark]
+//     Ci = np.hstack([Ci, new_features]);  Fi = np.hstack([Fi, new_features]);  Ti = np.hstack([Ti, tiled_pose])
+// One block, order-preserving throughout (numpy's boolean indexing keeps order): the candidates are walked in chunks of
+// 1024 with ballot / popcount offsets; a chunk's loads have returned before its first store and stores only go to
+// positions at or before the chunk's own, so C / F / T are compacted in place.  The promoted points and their 3-D
+// positions also go to new_P / new_X (which may be pinned host memory mapped into the device: the host appends them to
+// its own landmark arrays), the next frame's tracking input [landmarks | candidates] is laid out in track_next, and
+// counts = {promoted, candidates out, landmarks out, overflow} tells the host what happened.
+template <typename F>
+__global__ __launch_bounds__(1024) void candidate_commit_kernel(float2* C, F* Fp, double* T, int tdim, int m, int cap_c,
+                                                                const uint8_t* __restrict__ promote, const double* __restrict__ xyz,
+                                                                const float2* __restrict__ feat, const uint8_t* __restrict__ fmask, int nf,
+                                                                const double* __restrict__ pose, float2* P, int k, int cap_p,
+                                                                float2* __restrict__ track_next, float2* __restrict__ new_P,
+                                                                double* __restrict__ new_X, int* __restrict__ counts) {
+    __shared__ int wave_a[16], wave_b[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int n_keep = 0, n_prom = 0, overflow = 0;
+    for (int c0 = 0; c0 < m; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        bool keep = false, prom = false;
+        float2 c = make_float2(0.f, 0.f);
+        F fx = 0, fy = 0;
+        double t[16], X[3] = {0, 0, 0};
+        if (i < m) {
+            prom = promote[i] != 0;
+            keep = !prom;
+            c = C[i];
+            if (keep) {
+                fx = Fp[2 * (size_t)i]; fy = Fp[2 * (size_t)i + 1];
+                for (int q = 0; q < 16; ++q) if (q < tdim) t[q] = T[(size_t)i * tdim + q];
+            } else {
+                X[0] = xyz[3 * (size_t)i]; X[1] = xyz[3 * (size_t)i + 1]; X[2] = xyz[3 * (size_t)i + 2];
+            }
+        }
+        const unsigned long long bk = __ballot(keep), bp = __ballot(prom);
+        if (lane == 0) { wave_a[wave] = __popcll(bk); wave_b[wave] = __popcll(bp); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's loads have returned before anyone stores
+        __syncthreads();
+        int ok = n_keep + __popcll(bk & ((1ull << lane) - 1)), op = n_prom + __popcll(bp & ((1ull << lane) - 1)), tk = 0, tp = 0;
+        for (int q = 0; q < 16; ++q) {
+            ok += q < wave ? wave_a[q] : 0; tk += wave_a[q];
+            op += q < wave ? wave_b[q] : 0; tp += wave_b[q];
+        }
+        if (keep) {
+            C[ok] = c;
+            Fp[2 * (size_t)ok] = fx; Fp[2 * (size_t)ok + 1] = fy;
+            for (int q = 0; q < 16; ++q) if (q < tdim) T[(size_t)ok * tdim + q] = t[q];
+        }
+        if (prom) {
+            new_P[op] = c;
+            new_X[3 * (size_t)op] = X[0]; new_X[3 * (size_t)op + 1] = X[1]; new_X[3 * (size_t)op + 2] = X[2];
+            if (k + op < cap_p) P[k + op] = c; else overflow = 1;
+        }
+        n_keep += tk; n_prom += tp;
+        __syncthreads();
+    }
+    // new features: C = F = the detection, T = the current pose (continuous.py:487-493)
+    double pz[16];
+    for (int q = 0; q < 16; ++q) pz[q] = q < 12 && q < tdim ? pose[q] : 0.0;
+    int n_c = n_keep;
+    for (int c0 = 0; c0 < nf; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const bool add = i < nf && fmask[i] != 0;
+        const unsigned long long ba = __ballot(add);
+        if (lane == 0) wave_a[wave] = __popcll(ba);
+        __syncthreads();
+        int o = n_c + __popcll(ba & ((1ull << lane) - 1)), tot = 0;
+        for (int q = 0; q < 16; ++q) { o += q < wave ? wave_a[q] : 0; tot += wave_a[q]; }
+        if (add) {
+            if (o < cap_c) {
+                const float2 f = feat[i];
+                C[o] = f;
+                Fp[2 * (size_t)o] = (F)f.x; Fp[2 * (size_t)o + 1] = (F)f.y;
+                for (int q = 0; q < 16; ++q) if (q < tdim) T[(size_t)o * tdim + q] = pz[q];
+            } else overflow = 1;
+        }
+        n_c += tot;
+        __syncthreads();
+    }
+    const int k_out = min(k + n_prom, cap_p), m_out = min(n_c, cap_c);
+    overflow = __syncthreads_or(overflow || k + n_prom > cap_p || n_c > cap_c);
+    // next frame's tracking input: [landmarks | candidates]
+    for (int i = threadIdx.x; i < k_out; i += 1024) track_next[i] = P[i];
+    for (int i = threadIdx.x; i < m_out; i += 1024) track_next[k_out + i] = C[i];
+    if (threadIdx.x == 0) { counts[0] = n_prom; counts[1] = m_out; counts[2] = k_out; counts[3] = overflow; }
+}
+
 }  // namespace
 
 // smallest x >= 0 with sqrt(x) > t (host sqrt is correctly rounded); NaN when no distance can pass
@@ -273,13 +371,14 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
 }
 
 int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
-                                 const float* d_existing_xy, int n_existing, double threshold,
-                                 uint8_t* d_mask) {
+                                 const float* d_existing_xy, int n_existing, const float* d_existing2_xy, int n_existing2,
+                                 double threshold, uint8_t* d_mask) {
     if (n_features == 0) return VOFE_OK;
     const double s_star = square_threshold<double>(threshold);
     hipLaunchKernelGGL(new_feature_mask_kernel, dim3((n_features + 3) / 4), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float2*>(d_features_xy), n_features,
-                       reinterpret_cast<const float2*>(d_existing_xy), n_existing, s_star, d_mask);
+                       reinterpret_cast<const float2*>(d_existing_xy), n_existing,
+                       reinterpret_cast<const float2*>(d_existing2_xy), n_existing2, s_star, d_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "new_feature_mask launch");
     return VOFE_OK;
@@ -298,5 +397,24 @@ int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_po
                            static_cast<const float*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "triangulate launch");
+    return VOFE_OK;
+}
+
+int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first_is_f64, double* d_T, int tdim, int m, int cap_c,
+                                 const uint8_t* d_promote, const double* d_xyz, const float* d_features, const uint8_t* d_fmask,
+                                 int nf, const double* d_pose, float* d_P, int k, int cap_p, float* d_track_next, float* d_new_P,
+                                 double* d_new_X, int* d_counts) {
+    if (first_is_f64)
+        hipLaunchKernelGGL(candidate_commit_kernel<double>, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<float2*>(d_C),
+                           static_cast<double*>(d_F), d_T, tdim, m, cap_c, d_promote, d_xyz, reinterpret_cast<const float2*>(d_features),
+                           d_fmask, nf, d_pose, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
+                           reinterpret_cast<float2*>(d_new_P), d_new_X, d_counts);
+    else
+        hipLaunchKernelGGL(candidate_commit_kernel<float>, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<float2*>(d_C),
+                           static_cast<float*>(d_F), d_T, tdim, m, cap_c, d_promote, d_xyz, reinterpret_cast<const float2*>(d_features),
+                           d_fmask, nf, d_pose, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
+                           reinterpret_cast<float2*>(d_new_P), d_new_X, d_counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vofe_hip_fail(e, "candidate_commit launch");
     return VOFE_OK;
 }

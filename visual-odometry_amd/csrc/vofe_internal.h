@@ -112,8 +112,8 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
                              size_t img_stride, int harris, float k, float* d_score,
                              unsigned* d_max_keys, const uint8_t* d_mask);
 int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
-                                 const float* d_existing_xy, int n_existing, double threshold,
-                                 uint8_t* d_mask);
+                                 const float* d_existing_xy, int n_existing, const float* d_existing2_xy, int n_existing2,
+                                 double threshold, uint8_t* d_mask);
 int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status, const void* d_first_xy,
                                  int first_is_f64, const double* d_transform, int tdim, int n, double dist_min,
                                  double dist_max, double dist_tri, float* d_tracked_out, void* d_first_out,
@@ -121,6 +121,10 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
 int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy, const void* d_first_xy,
                             int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in, int n,
                             double alpha_min, uint8_t* d_flag_out, double* d_xyz);
+int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first_is_f64, double* d_T, int tdim, int m, int cap_c,
+                                 const uint8_t* d_promote, const double* d_xyz, const float* d_features, const uint8_t* d_fmask,
+                                 int nf, const double* d_pose, float* d_P, int k, int cap_p, float* d_track_next, float* d_new_P,
+                                 double* d_new_X, int* d_counts);
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
