@@ -135,13 +135,15 @@ __device__ __forceinline__ u32x3 gload_u96(gbase_t b, unsigned off) { return *((
 // Diagnostic build only (-DLK_STAMPS): s_memtime deltas per phase, written to counters[8 + 8*block + k]
 // for the first 256 blocks.  Never enabled in the shipped library.
 #ifdef LK_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = 0;
-#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_END(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned st_t0 = 0;
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); st_t0 = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_END(k) do { __builtin_amdgcn_sched_barrier(0); unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_N 12
 #else
 #define STAMP_DECL
 #define STAMP_BEGIN() do {} while (0)
 #define STAMP_END(k) do {} while (0)
+#define STAMP_N 1
 #endif
 
 // ---- staging of the search image J into LDS -------------------------------------------------
@@ -225,7 +227,7 @@ template <int R, int WC>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* lds, int lane, int x, int y0,
-                                       int ny, unsigned& n_lv, unsigned& n_it, unsigned long long* st_acc) {
+                                       int ny, unsigned& n_lv, unsigned& n_it, unsigned* st_acc) {
     STAMP_DECL
     (void)st_acc;
     constexpr bool REG = WC != 0 && WC % R == 0;
@@ -239,6 +241,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
     const int tasks = (WC ? WC + 1 + 2 * LK_MARGIN : a.rh) * segs;
 #define LK_ROW(r) (REG ? (r) : min((r), ny))
     for (int level = top; level >= 0; --level) {
+        STAMP_BEGIN();
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
         const float sc = 1.0f / (float)(1 << level);
@@ -256,7 +259,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             continue;
         }
         ++n_lv;
-        STAMP_BEGIN();
+        STAMP_END(8);
         // prefetch the search region around the start position (loads only; written to LDS after the
         // template window has been computed, so both memory latencies overlap)
         const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
@@ -386,6 +389,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             }
             pdx = dx; pdy = dy;
         }
+        STAMP_BEGIN();
         if (status && level == 0 && !(flags & 8) && !(flags & LK_NO_ERR)) {
             const float ex = outx - hx, ey = outy - hy;
             const int inx = floor_i(ex), iny = floor_i(ey);
@@ -413,6 +417,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             err = wave_sum_to_float(se) / (float)(32 * w * h);
         }
         __syncthreads();     // all LDS reads of this level done before the next level restages
+        STAMP_END(9);
     }
 }
 
@@ -422,6 +427,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 template <int R, int WC>
 __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     extern __shared__ unsigned lds[];
+#ifdef LK_STAMPS
+    const unsigned long long st_wave0 = __builtin_amdgcn_s_memtime();
+#endif
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int ww = WC ? WC : a.win_w, wh = WC ? WC : a.win_h;
@@ -444,7 +452,11 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
     float bx = 0.f, by = 0.f;
     const int ndir = bad_idx ? 0 : (a.fb ? 2 : 1);
     unsigned n_lv = 0, n_it = 0;
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned st_acc[STAMP_N] = {};
+#ifdef LK_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);                                               // the point and its image index have arrived
+    st_acc[10] = (unsigned)(__builtin_amdgcn_s_memtime() - st_wave0);                        // kernel prologue
+#endif
     for (int dir = 0; dir < ndir; ++dir) {      // dir 1 = backward pass from the forward result
         const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
         const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
@@ -475,7 +487,8 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
             atomicAdd(a.counters + 1, (unsigned long long)n_lv);
             atomicAdd(a.counters + 2, (unsigned long long)n_it);
 #ifdef LK_STAMPS
-            if (blockIdx.x < 256) for (int k = 0; k < 8; ++k) a.counters[8 + 8 * blockIdx.x + k] = st_acc[k];
+            st_acc[7] = (unsigned)(__builtin_amdgcn_s_memtime() - st_wave0);            // whole wavefront
+            if (blockIdx.x < 256) for (int k = 0; k < STAMP_N; ++k) a.counters[8 + STAMP_N * blockIdx.x + k] = st_acc[k];
 #endif
         }
     }
