@@ -233,6 +233,62 @@ int vofe_candidate_commit(vofe_ctx* ctx, float* d_cand_xy, void* d_first_xy, int
                           float* d_landmarks_xy, int n_landmarks, int cap_landmarks, float* d_track_next, float* d_new_landmarks_xy,
                           double* d_new_landmarks_xyz, int* d_counts);
 
+/* ---- frame state resident on the device (SURVEY.md 8f ranks 1-4 as one object) ------------------
+ * Replaces, for one sequence, what ContinuousVO.process_frame (reference continuous.py:73-114) asks of the front end
+ * per frame: landmark tracking (:86-92), and _handle_candidates (:349-495: detection, candidate tracking, status
+ * compaction, travel-distance band, cdist de-duplication, triangulation, promotion, append).  The image-point arrays
+ * of the reference's FrameState (framestate.py:13-78: landmarks Pi, candidates Ci / Fi / Ti) live in device memory
+ * across frames; a frame is two calls around the caller's CPU pose estimation (continuous.py:166-272), one host wait
+ * each.  All pointers of this group are HOST pointers (the reference holds numpy arrays); arrays are row-major with
+ * one point per row: (K,2) f32 image points, (K,3) f64 world points, (M,12) f64 first-observation poses, first
+ * observations (M,2) in f64 or f32 as `first_is_f64` says (numpy keeps whichever dtype the caller's FrameState has).
+ * The object owns its contexts and streams (non-blocking), is bound to one device and is not thread-safe. */
+typedef struct vofe_framestate vofe_framestate;
+typedef struct vofe_framestate_params {
+    int height, width;
+    int win_w, win_h, max_level;                /* LK: continuous.py:24-29, 137-141 */
+    int crit_type, max_count;
+    double eps, min_eig_thr;
+    float fb_thresh;                            /* continuous.py:158: 1.0 */
+    int max_corners;                            /* goodFeaturesToTrack: continuous.py:380-385; must be positive */
+    double quality_level, min_distance;
+    double thr_new_keypoints;                   /* constants.py THRESHOLD_NEW_KEYPOINTS (continuous.py:413) */
+    double thr_triangulation;                   /* THRESHOLD_PIXEL_DIST_TRIANGULATION (:448) */
+    double thr_candidates_min, thr_candidates_max;   /* MIN / MAX travel distance (:400-401) */
+    double thr_alpha_rad;                       /* minimum baseline angle (:475, :274-309), radians */
+    int cap_landmarks, cap_candidates;          /* capacities of the device arrays; exceeding one is VOFE_E_NOMEM */
+    int first_is_f64;
+    double K[9];                                /* intrinsics, row-major */
+} vofe_framestate_params;
+
+int vofe_framestate_create(int device, const vofe_framestate_params* params, vofe_framestate** out);
+int vofe_framestate_destroy(vofe_framestate* fs);
+/* Start from a FrameState on its frame (reference main.py:82-90 builds the first one): uploads the frame, builds its
+ * pyramid, uploads the point arrays.  h_img: height rows of width bytes, `pitch` bytes apart. */
+int vofe_framestate_reset(vofe_framestate* fs, const uint8_t* h_img, int pitch, const float* h_landmarks_xy,
+                          const double* h_landmarks_xyz, int n_landmarks, const float* h_cand_xy, const void* h_first_xy,
+                          const double* h_transform, int n_candidates);
+/* Pinned staging buffer (height x width, contiguous) the NEXT frame may be written into directly -- e.g. by the image
+ * decoder -- so that vofe_framestate_track(fs, that pointer, width, ...) skips its host-side copy. */
+int vofe_framestate_frame_buffer(vofe_framestate* fs, uint8_t** h_buf);
+/* Phase 1 (continuous.py:86-87, 380-405): upload, ONE pyramid, ONE forward-backward launch over [landmarks | candidates],
+ * candidate compaction + distance band, detection on a second stream; one wait.  *h_tracked_xy / *h_status point into
+ * pinned memory owned by the object ((K,2) f32 and (K) u8 for the K landmarks, valid until the next call on fs);
+ * *n_landmarks = K; *n_features / *n_candidates_kept (may be NULL) report the detections and surviving candidates. */
+int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, const float** h_tracked_xy,
+                          const uint8_t** h_status, int* n_landmarks, int* n_features, int* n_candidates_kept);
+/* Phase 2 (continuous.py:90-101 selection by h_keep, a (K) u8 mask = tracked AND kept by the pose estimation;
+ * :408-495 de-duplication, triangulation, promotion, append).  h_pose: 3x4 row-major f64.  World points of the kept
+ * and the promoted landmarks are maintained on the host side of the object (only the CPU pose estimation reads them).
+ * *n_promoted may be NULL. */
+int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep, int* n_promoted);
+int vofe_framestate_counts(const vofe_framestate* fs, int* n_landmarks, int* n_candidates);
+/* World points (K,3) f64 of the current landmarks, in landmark order (pointer valid until the next update/reset). */
+int vofe_framestate_landmarks_world(const vofe_framestate* fs, const double** h_xyz, int* n_landmarks);
+/* The FrameState arrays as the reference holds them (any pointer may be NULL); synchronous; not between track and update. */
+int vofe_framestate_download(vofe_framestate* fs, float* h_landmarks_xy, float* h_cand_xy, void* h_first_xy,
+                             double* h_transform);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1008,6 +1008,77 @@ def test_device_resident_frame_state_follows_the_reference_frame_loop(fe):
     st.close()
 
 
+def test_native_frame_state_edges_float32_staging_buffer_empty_and_overflow(fe):
+    """vofe_framestate through the C ABI beyond the main sequence test: float32 first observations (numpy then evaluates
+    the distance band in float32, continuous.py:398-401), frames written straight into the object's pinned staging
+    buffer, a start without landmarks, the reference's ValueError when detections meet an empty state, the capacity
+    error, and the call-order checks."""
+    from visual_odometry_amd import DeviceFrameState
+    H, W = 240, 320
+    frames = _seq(H, W, 11, 5)
+    K = np.array([[300.0, 0, 160], [0, 300.0, 120], [0, 0, 1.0]])
+
+    def pose_at(t):
+        T = np.eye(4)
+        T[:3, 3] = [0.05 * t, 0.0, 0.8 * t]
+        return T
+
+    kw = dict(max_corners=300, quality_level=0.01, min_distance=8, threshold_alpha_deg=0.02, threshold_triangulation=3)
+    lk = dict(winSize=(15, 15), maxLevel=2)
+    first = oracle.goodFeaturesToTrack(frames[0], 300, 0.01, 8).reshape(-1, 2)
+    Ci, Fi = first.T.copy(), first.T.copy()                      # float32 first observations
+    Ti = np.tile(pose_at(0)[:3, :].reshape(-1, 1), (1, Ci.shape[1]))
+    Pi, Xi = np.empty((2, 0), np.float32), np.empty((3, 0))
+    st = DeviceFrameState(H, W, K, first_dtype=np.float32, cap_landmarks=512, cap_candidates=1024, **lk, **kw)
+    with pytest.raises(Exception):
+        st.track(frames[1])                                      # track() before reset()
+    st.reset(frames[0], Pi, Xi, Ci, Fi, Ti)
+    assert st.K == 0 and st.M == Ci.shape[1]
+    promoted = 0
+    for t in range(1, 5):
+        st.frame_buffer[...] = frames[t]                         # "the decoder" writes into pinned memory
+        gt, gs = st.track(st.frame_buffer)
+        rt, rs, _ = oracle.track_keypoints(Pi, frames[t - 1], frames[t], **lk)
+        assert gt.shape == (2, Pi.shape[1]) and np.array_equal(gt, rt) and np.array_equal(gs, rs), t
+        with pytest.raises(Exception):
+            st.track(frames[t])                                  # twice without update()
+        with pytest.raises(Exception):
+            st.download()                                        # between the phases
+        keep = rs == 1
+        Pi, Xi = rt[:, keep].astype(np.float32), Xi[:, keep]
+        with np.errstate(all="ignore"):
+            rPi, rXi, Ci, Fi, Ti = oracle.handle_candidates(K, frames[t], frames[t - 1], Ci, Fi, Ti, Pi, Xi, pose_at(t), lk_params=lk, **kw)
+        promoted += st.update(pose_at(t), keep)
+        gPi, gXi, gCi, gFi, gTi = st.download()
+        assert gFi.dtype == np.float32 and Fi.dtype == np.float32
+        for name, g, r in (("Pi", gPi, rPi), ("Ci", gCi, Ci), ("Fi", gFi, Fi), ("Ti", gTi, Ti)):
+            assert g.shape == r.shape and np.array_equal(g, r), (t, name, g.shape, r.shape)
+        assert gXi.shape == rXi.shape and np.allclose(gXi, rXi, rtol=2e-3, atol=2e-2), t      # float32 points4D
+        Pi, Xi = rPi, rXi
+    assert promoted > 0 and Pi.shape[1] == promoted
+    # an empty state meeting detections: the reference's np.min over an empty axis raises ValueError
+    st.reset(frames[0], np.empty((2, 0)), np.empty((3, 0)))
+    gt, gs = st.track(frames[1])
+    assert gt.shape == (2, 0) and gs.shape == (0,)
+    with pytest.raises(ValueError):
+        st.update(pose_at(1), np.empty(0, bool))
+    st.close()
+    # capacity: more new candidates than the arrays hold
+    import visual_odometry_amd
+    assert first.shape[0] > 100
+    small = DeviceFrameState(H, W, K, cap_landmarks=64, cap_candidates=64, **lk, **kw)
+    with pytest.raises(visual_odometry_amd.error):
+        small.reset(frames[0], first[:4].T, np.zeros((3, 4)), Ci[:, :65], Fi[:, :65], Ti[:, :65])      # over capacity at the start
+    small.reset(frames[0], first[:4].T, np.zeros((3, 4)))
+    _, s = small.track(frames[1])
+    with pytest.raises(visual_odometry_amd.error) as ei:
+        small.update(pose_at(1), s == 1)                         # ~300 detections into 64 candidate slots
+    assert ei.value.code == -4
+    with pytest.raises(Exception):
+        small.track(frames[1])                                   # the state has to be reset after an overflow
+    small.close()
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -13,7 +13,20 @@ SYMBOLS = (
     "vofe_pyramid_level_size", "vofe_pyramid_download", "vofe_pyramid_download_padded",
     "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_profile_begin", "vofe_profile_end", "vofe_corner_score", "vofe_gftt", "vofe_gftt_host", "vofe_gftt_batch", "vofe_gftt_noalloc", "vofe_new_feature_mask", "vofe_new_feature_mask2",
     "vofe_candidate_filter", "vofe_triangulate_candidates", "vofe_candidate_commit",
+    "vofe_framestate_create", "vofe_framestate_destroy", "vofe_framestate_reset", "vofe_framestate_frame_buffer",
+    "vofe_framestate_track", "vofe_framestate_update", "vofe_framestate_counts", "vofe_framestate_landmarks_world",
+    "vofe_framestate_download",
 )
+
+
+class FrameStateParams(C.Structure):
+    """vofe_framestate_params of include/vofe.h, field for field."""
+    _fields_ = [("height", C.c_int), ("width", C.c_int), ("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
+                ("crit_type", C.c_int), ("max_count", C.c_int), ("eps", C.c_double), ("min_eig_thr", C.c_double),
+                ("fb_thresh", C.c_float), ("max_corners", C.c_int), ("quality_level", C.c_double), ("min_distance", C.c_double),
+                ("thr_new_keypoints", C.c_double), ("thr_triangulation", C.c_double), ("thr_candidates_min", C.c_double),
+                ("thr_candidates_max", C.c_double), ("thr_alpha_rad", C.c_double), ("cap_landmarks", C.c_int),
+                ("cap_candidates", C.c_int), ("first_is_f64", C.c_int), ("K", C.c_double * 9)]
 
 _lib = None
 
@@ -66,6 +79,15 @@ def load():
     L.vofe_triangulate_candidates.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, i, d, vp, vp]
     L.vofe_candidate_commit.argtypes = [vp, vp, vp, i, vp, i, i, i, vp, vp, vp, vp, i, vp, vp, i, i, vp, vp, vp, vp]
     L.vofe_gftt_batch.argtypes = [vp, vp, i, i, i, i, sz, i, d, d, i, i, i, d, vp, i, ip]
+    L.vofe_framestate_create.argtypes = [i, C.POINTER(FrameStateParams), C.POINTER(vp)]
+    L.vofe_framestate_destroy.argtypes = [vp]
+    L.vofe_framestate_reset.argtypes = [vp, vp, i, vp, vp, i, vp, vp, vp, i]
+    L.vofe_framestate_frame_buffer.argtypes = [vp, C.POINTER(vp)]
+    L.vofe_framestate_track.argtypes = [vp, vp, i, C.POINTER(vp), C.POINTER(vp), ip, ip, ip]
+    L.vofe_framestate_update.argtypes = [vp, vp, vp, ip]
+    L.vofe_framestate_counts.argtypes = [vp, ip, ip]
+    L.vofe_framestate_landmarks_world.argtypes = [vp, C.POINTER(vp), ip]
+    L.vofe_framestate_download.argtypes = [vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         if name != "vofe_last_error":
             getattr(L, name).restype = C.c_int
