@@ -282,9 +282,17 @@ int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
  * and the promoted landmarks are maintained on the host side of the object (only the CPU pose estimation reads them).
  * *n_promoted may be NULL. */
 int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep, int* n_promoted);
-int vofe_framestate_counts(const vofe_framestate* fs, int* n_landmarks, int* n_candidates);
+/* Phase 2 without its wait: queues the same work and returns; h_pose / h_keep are consumed before the call returns.  The
+ * update is collected by vofe_framestate_wait or by the next call that needs its outcome (track, counts,
+ * landmarks_world, download); vofe_framestate_track first copies, uploads and builds the pyramid of its frame and
+ * only then waits, so the update overlaps whatever the caller does between the two calls and the host copy of the next
+ * frame.  A capacity overflow of the queued update is reported (VOFE_E_NOMEM) by the call that collects it.
+ * vofe_framestate_update == vofe_framestate_update_async + vofe_framestate_wait. */
+int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep);
+int vofe_framestate_wait(vofe_framestate* fs, int* n_promoted);
+int vofe_framestate_counts(vofe_framestate* fs, int* n_landmarks, int* n_candidates);
 /* World points (K,3) f64 of the current landmarks, in landmark order (pointer valid until the next update/reset). */
-int vofe_framestate_landmarks_world(const vofe_framestate* fs, const double** h_xyz, int* n_landmarks);
+int vofe_framestate_landmarks_world(vofe_framestate* fs, const double** h_xyz, int* n_landmarks);
 /* The FrameState arrays as the reference holds them (any pointer may be NULL); synchronous; not between track and update. */
 int vofe_framestate_download(vofe_framestate* fs, float* h_landmarks_xy, float* h_cand_xy, void* h_first_xy,
                              double* h_transform);

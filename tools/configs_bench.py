@@ -153,7 +153,8 @@ def frame_loop(fe, cfg, md, n_land, n_cand, max_corners, n_frames=8, rounds=6):
         t0 = time.perf_counter()
         for t in range(1, n_frames):
             _, status = st.track(fr[t])
-            st.update(pose_at(t), status == 1)
+            st.update(pose_at(t), status == 1, wait=False)     # collected by the next track(), behind its frame upload
+        st.wait()
         dt = time.perf_counter() - t0
         sizes = (st.K, st.M)
         trk.reset(fr[0])

@@ -14,7 +14,7 @@ SYMBOLS = (
     "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_profile_begin", "vofe_profile_end", "vofe_corner_score", "vofe_gftt", "vofe_gftt_host", "vofe_gftt_batch", "vofe_gftt_noalloc", "vofe_new_feature_mask", "vofe_new_feature_mask2",
     "vofe_candidate_filter", "vofe_triangulate_candidates", "vofe_candidate_commit",
     "vofe_framestate_create", "vofe_framestate_destroy", "vofe_framestate_reset", "vofe_framestate_frame_buffer",
-    "vofe_framestate_track", "vofe_framestate_update", "vofe_framestate_counts", "vofe_framestate_landmarks_world",
+    "vofe_framestate_track", "vofe_framestate_update", "vofe_framestate_update_async", "vofe_framestate_wait", "vofe_framestate_counts", "vofe_framestate_landmarks_world",
     "vofe_framestate_download",
 )
 
@@ -85,6 +85,8 @@ def load():
     L.vofe_framestate_frame_buffer.argtypes = [vp, C.POINTER(vp)]
     L.vofe_framestate_track.argtypes = [vp, vp, i, C.POINTER(vp), C.POINTER(vp), ip, ip, ip]
     L.vofe_framestate_update.argtypes = [vp, vp, vp, ip]
+    L.vofe_framestate_update_async.argtypes = [vp, vp, vp]
+    L.vofe_framestate_wait.argtypes = [vp, ip]
     L.vofe_framestate_counts.argtypes = [vp, ip, ip]
     L.vofe_framestate_landmarks_world.argtypes = [vp, C.POINTER(vp), ip]
     L.vofe_framestate_download.argtypes = [vp, vp, vp, vp, vp]

@@ -41,7 +41,8 @@ struct vofe_framestate {
     size_t o_cnt, o_newP, o_newX;  // byte offsets of the counters / promoted landmarks in the result buffer
     // host side
     double* world;                 // (capP, 3) world points of the landmarks
-    int K, M, m1, nf, phase, frame_index;
+    int K, M, m1, nf, phase, frame_index;     // phase: 0 idle, 1 tracked (update is due), 2 update queued (not yet collected)
+    int K1, last_promoted;                    // landmarks the pose estimation kept; promoted by the last collected update
 };
 
 namespace {
@@ -92,6 +93,24 @@ int push_frame(vofe_framestate* fs, const uint8_t* h_img, int pitch) {
     int rc = vofe_pyramid_build(fs->c_trk, fs->pyr, slot, 1, fs->d_img[slot], w, 0);
     if (rc) return rc;
     fs->frame_index += 1;
+    return VOFE_OK;
+}
+
+// the host half of phase 2: wait for the queued update, take its counts, append the promoted world points
+int collect_update(vofe_framestate* fs) {
+    if (fs->phase != 2) return VOFE_OK;
+    VOFE_HIP(hipStreamSynchronize(fs->s_trk));
+    const int* cnt = reinterpret_cast<const int*>(fs->h_res + fs->o_cnt) + 4;
+    const int n_prom = cnt[0], m_out = cnt[1], k_out = cnt[2], overflow = cnt[3];
+    if (overflow) {
+        fs->K = fs->M = 0; fs->phase = 0; fs->frame_index = -1;      // the arrays were cut at their capacity: start over
+        vofe_set_error("vofe_framestate_update: landmark / candidate capacity exceeded (%d / %d); the state needs vofe_framestate_reset",
+                       fs->p.cap_landmarks, fs->p.cap_candidates);
+        return VOFE_E_NOMEM;
+    }
+    if (n_prom) memcpy(fs->world + (size_t)fs->K1 * 3, fs->h_res + fs->o_newX, (size_t)n_prom * 24);
+    fs->K = k_out; fs->M = m_out; fs->phase = 0;
+    fs->last_promoted = n_prom;
     return VOFE_OK;
 }
 
@@ -199,7 +218,7 @@ int vofe_framestate_reset(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
     }
     int rc = bind(fs);
     if (rc) return rc;
-    VOFE_HIP(hipStreamSynchronize(fs->s_trk));
+    VOFE_HIP(hipStreamSynchronize(fs->s_trk));       // a queued update is dropped with the state it belongs to
     fs->frame_index = -1;
     fs->phase = 0;
     rc = push_frame(fs, h_img, pitch);
@@ -224,13 +243,17 @@ int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
                           const uint8_t** h_status, int* n_landmarks, int* n_features, int* n_candidates_kept) {
     if (!fs || !h_img || !h_tracked_xy || !h_status || !n_landmarks) { vofe_set_error("vofe_framestate_track: NULL argument"); return VOFE_E_ARG; }
     if (fs->frame_index < 0) { vofe_set_error("vofe_framestate_track before vofe_framestate_reset"); return VOFE_E_ARG; }
-    if (fs->phase != 0) { vofe_set_error("vofe_framestate_track called twice without vofe_framestate_update"); return VOFE_E_ARG; }
+    if (fs->phase == 1) { vofe_set_error("vofe_framestate_track called twice without vofe_framestate_update"); return VOFE_E_ARG; }
     if (pitch < fs->p.width) { vofe_set_error("vofe_framestate_track: pitch %d < width %d", pitch, fs->p.width); return VOFE_E_ARG; }
     int rc = bind(fs);
     if (rc) return rc;
     const vofe_framestate_params& p = fs->p;
     const int prev_slot = fs->frame_index & 1;
+    // staging copy, upload and pyramid of the new frame do not depend on the point counts: they are queued (and the
+    // host copy made) BEFORE the wait for an update that vofe_framestate_update_async left running
     rc = push_frame(fs, h_img, pitch);
+    if (rc) return rc;
+    rc = collect_update(fs);
     if (rc) return rc;
     const int slot = fs->frame_index & 1;
     // detection (continuous.py:380-385) needs the uploaded frame only: queue its stream behind the copy, not behind the
@@ -270,8 +293,7 @@ int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
     return VOFE_OK;
 }
 
-int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep, int* n_promoted) {
-    if (n_promoted) *n_promoted = 0;
+int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep) {
     if (!fs || !h_pose) { vofe_set_error("vofe_framestate_update: NULL argument"); return VOFE_E_ARG; }
     if (fs->phase != 1) { vofe_set_error("vofe_framestate_update before vofe_framestate_track"); return VOFE_E_ARG; }
     if (fs->K > 0 && !h_keep) { vofe_set_error("vofe_framestate_update: keep mask is NULL"); return VOFE_E_ARG; }
@@ -315,31 +337,44 @@ int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint
                                reinterpret_cast<float*>(fs->d_res + fs->o_newP), reinterpret_cast<double*>(fs->d_res + fs->o_newX),
                                reinterpret_cast<int*>(fs->d_res + fs->o_cnt) + 4);
     if (rc) return rc;
-    VOFE_HIP(hipStreamSynchronize(st));
-    const int* cnt = reinterpret_cast<const int*>(fs->h_res + fs->o_cnt) + 4;
-    const int n_prom = cnt[0], m_out = cnt[1], k_out = cnt[2], overflow = cnt[3];
-    if (overflow) {
-        fs->K = fs->M = 0; fs->phase = 0; fs->frame_index = -1;      // the arrays were cut at their capacity: start over
-        vofe_set_error("vofe_framestate_update: landmark / candidate capacity exceeded (%d / %d); the state needs vofe_framestate_reset",
-                       p.cap_landmarks, p.cap_candidates);
-        return VOFE_E_NOMEM;
-    }
-    if (n_prom) memcpy(fs->world + (size_t)K1 * 3, fs->h_res + fs->o_newX, (size_t)n_prom * 24);
-    fs->K = k_out; fs->M = m_out; fs->phase = 0;
-    if (n_promoted) *n_promoted = n_prom;
+    fs->K1 = K1;
+    fs->phase = 2;
     return VOFE_OK;
 }
 
-int vofe_framestate_counts(const vofe_framestate* fs, int* n_landmarks, int* n_candidates) {
+int vofe_framestate_wait(vofe_framestate* fs, int* n_promoted) {
+    if (n_promoted) *n_promoted = 0;
+    if (!fs) { vofe_set_error("vofe_framestate_wait: NULL argument"); return VOFE_E_ARG; }
+    int rc = bind(fs);
+    if (rc) return rc;
+    rc = collect_update(fs);
+    if (rc) return rc;
+    if (n_promoted) *n_promoted = fs->last_promoted;
+    return VOFE_OK;
+}
+
+int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep, int* n_promoted) {
+    if (n_promoted) *n_promoted = 0;
+    int rc = vofe_framestate_update_async(fs, h_pose, h_keep);
+    if (rc) return rc;
+    return vofe_framestate_wait(fs, n_promoted);
+}
+
+int vofe_framestate_counts(vofe_framestate* fs, int* n_landmarks, int* n_candidates) {
     if (!fs) { vofe_set_error("vofe_framestate_counts: NULL argument"); return VOFE_E_ARG; }
+    if (fs->phase == 1) { vofe_set_error("vofe_framestate_counts between track and update"); return VOFE_E_ARG; }
+    int rc = collect_update(fs);
+    if (rc) return rc;
     if (n_landmarks) *n_landmarks = fs->K;
     if (n_candidates) *n_candidates = fs->M;
     return VOFE_OK;
 }
 
-int vofe_framestate_landmarks_world(const vofe_framestate* fs, const double** h_xyz, int* n_landmarks) {
+int vofe_framestate_landmarks_world(vofe_framestate* fs, const double** h_xyz, int* n_landmarks) {
     if (!fs || !h_xyz || !n_landmarks) { vofe_set_error("vofe_framestate_landmarks_world: NULL argument"); return VOFE_E_ARG; }
-    if (fs->phase != 0) { vofe_set_error("vofe_framestate_landmarks_world between track and update"); return VOFE_E_ARG; }
+    if (fs->phase == 1) { vofe_set_error("vofe_framestate_landmarks_world between track and update"); return VOFE_E_ARG; }
+    int rc0 = collect_update(fs);
+    if (rc0) return rc0;
     *h_xyz = fs->world;
     *n_landmarks = fs->K;
     return VOFE_OK;
@@ -348,8 +383,10 @@ int vofe_framestate_landmarks_world(const vofe_framestate* fs, const double** h_
 int vofe_framestate_download(vofe_framestate* fs, float* h_landmarks_xy, float* h_cand_xy, void* h_first_xy,
                              double* h_transform) {
     if (!fs) { vofe_set_error("vofe_framestate_download: NULL argument"); return VOFE_E_ARG; }
-    if (fs->phase != 0) { vofe_set_error("vofe_framestate_download between track and update"); return VOFE_E_ARG; }
+    if (fs->phase == 1) { vofe_set_error("vofe_framestate_download between track and update"); return VOFE_E_ARG; }
     int rc = bind(fs);
+    if (rc) return rc;
+    rc = collect_update(fs);
     if (rc) return rc;
     hipStream_t st = fs->s_trk;
     const size_t K = fs->K, M = fs->M;

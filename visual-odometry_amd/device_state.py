@@ -127,21 +127,28 @@ class DeviceFrameState:
         return tracked.T, status
 
     # ------------------------------------------------------------------------------------------------ phase 2
-    def update(self, pose, keep):
+    def update(self, pose, keep, wait=True):
         """Reference continuous.py:90-92 + the inlier selection of :95-101 (keep = status == 1 and kept by the pose
         estimation, a (K,) mask) and :408-495: de-duplication, triangulation, promotion, new candidates.
-        Returns the number of promoted candidates."""
+        Returns the number of promoted candidates; with wait=False the work is only queued (returns None) and is
+        collected by wait() or by whichever call needs its outcome next -- track() overlaps it with the copy, upload
+        and pyramid of its frame."""
         keep = np.ascontiguousarray(np.asarray(keep).reshape(-1) != 0).view(np.uint8)
         if keep.shape[0] != self._n_tracked:
             raise error(-1, "keep mask must have one entry per landmark")
         pose = np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4])
-        n_prom = C.c_int()
-        rc = self.L.vofe_framestate_update(self._h, pose.ctypes.data, keep.ctypes.data, C.byref(n_prom))
+        rc = self.L.vofe_framestate_update_async(self._h, pose.ctypes.data, keep.ctypes.data)
         if rc:
             msg = self.L.vofe_last_error().decode("utf-8", "replace")
             if msg.startswith("zero-size array"):
                 raise ValueError(msg)                  # what np.min(cdist(...), axis=1) raises in the reference
             raise error(rc, msg)
+        return self.wait() if wait else None
+
+    def wait(self):
+        """Collect a queued update; returns the number of candidates it promoted."""
+        n_prom = C.c_int()
+        _lib.check(self.L.vofe_framestate_wait(self._h, C.byref(n_prom)))
         return n_prom.value
 
     def close(self):
