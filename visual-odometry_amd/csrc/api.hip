@@ -37,6 +37,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->pad_copy_generic = env_is("VOFE_PAD_COPY", 'g');
     k->score_tile = env_is("VOFE_CORNER_SCORE", 't');
     k->score_rs = env_int("VOFE_SCORE_RS", 0);
+    k->nms_rows = env_int("VOFE_NMS_ROWS", 0);
     k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
     if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : 0;
@@ -511,7 +512,7 @@ int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* 
         return VOFE_E_ARG;
     }
     VOFE_BIND(ctx);
-    return vofe_launch_triangulate(ctx, d_K, d_pose, d_cur_xy, d_first_xy, first_is_f64, d_transform, transform_dim, d_flag_in, n,
+    return vofe_launch_triangulate(ctx, d_K, d_pose, nullptr, d_cur_xy, d_first_xy, first_is_f64, d_transform, transform_dim, d_flag_in, n,
                                    alpha_min, d_flag_out, d_xyz);
 }
 
@@ -534,7 +535,7 @@ int vofe_candidate_commit(vofe_ctx* ctx, float* d_cand_xy, void* d_first_xy, int
     }
     VOFE_BIND(ctx);
     return vofe_launch_candidate_commit(ctx, d_cand_xy, d_first_xy, first_is_f64, d_transform, transform_dim, n_candidates, cap_candidates,
-                                        d_promote, d_xyz, d_features_xy, d_feature_mask, n_features, d_pose, d_landmarks_xy, n_landmarks,
+                                        d_promote, d_xyz, d_features_xy, d_feature_mask, n_features, d_pose, nullptr, d_landmarks_xy, n_landmarks,
                                         cap_landmarks, d_track_next, d_new_landmarks_xy, d_new_landmarks_xyz, d_counts);
 }
 

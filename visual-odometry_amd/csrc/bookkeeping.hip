@@ -13,6 +13,7 @@
 // minimum and compares, in float64, in scipy's operation order.  A NaN distance makes np.min NaN and
 // the comparison false; the kernel tracks that separately.
 #include <cmath>
+#include <cstring>
 
 #include "vofe_internal.h"
 
@@ -144,7 +145,7 @@ __device__ void k_times(const double* K, const double* M, double* P) {   // P (3
 }
 
 template <typename F>
-__global__ __launch_bounds__(64) void triangulate_kernel(const double* __restrict__ Kmat, const double* __restrict__ pose,
+__global__ __launch_bounds__(64) void triangulate_kernel(const double* __restrict__ Kmat, const double* __restrict__ pose, VofePoseK pk,
                                                          const float2* __restrict__ cur, const F* __restrict__ first,
                                                          const double* __restrict__ transform, int tdim,
                                                          const uint8_t* __restrict__ flag_in, int n, double alpha_min,
@@ -153,10 +154,11 @@ __global__ __launch_bounds__(64) void triangulate_kernel(const double* __restric
     if (i >= n) return;
     if (!flag_in[i]) { flag_out[i] = 0; return; }
     double K[9], T2[12], T1[12], M[12], P1[12], P2[12];
+    // pose and intrinsics from device memory, or (both pointers null) from the kernel arguments
 #pragma unroll
-    for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
+    for (int k = 0; k < 9; ++k) K[k] = Kmat ? Kmat[k] : pk.K[k];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { T2[k] = pose[k]; T1[k] = transform[(size_t)i * tdim + k]; }
+    for (int k = 0; k < 12; ++k) { T2[k] = pose ? pose[k] : pk.pose[k]; T1[k] = transform[(size_t)i * tdim + k]; }
     invert_rt(T1, M); k_times(K, M, P1);
     invert_rt(T2, M); k_times(K, M, P2);
     const double x1 = (double)first[2 * (size_t)i], y1 = (double)first[2 * (size_t)i + 1];
@@ -239,7 +241,7 @@ template <typename F>
 __global__ __launch_bounds__(1024) void candidate_commit_kernel(float2* C, F* Fp, double* T, int tdim, int m, int cap_c,
                                                                 const uint8_t* __restrict__ promote, const double* __restrict__ xyz,
                                                                 const float2* __restrict__ feat, const uint8_t* __restrict__ fmask, int nf,
-                                                                const double* __restrict__ pose, float2* P, int k, int cap_p,
+                                                                const double* __restrict__ pose, VofePoseK pk, float2* P, int k, int cap_p,
                                                                 float2* __restrict__ track_next, float2* __restrict__ new_P,
                                                                 double* __restrict__ new_X, int* __restrict__ counts) {
     __shared__ int wave_a[16], wave_b[16];
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(1024) void candidate_commit_kernel(float2* C, F* Fp
     }
     // new features: C = F = the detection, T = the current pose (continuous.py:487-493)
     double pz[16];
-    for (int q = 0; q < 16; ++q) pz[q] = q < 12 && q < tdim ? pose[q] : 0.0;
+    for (int q = 0; q < 16; ++q) pz[q] = q < 12 && q < tdim ? (pose ? pose[q] : pk.pose[q]) : 0.0;
     int n_c = n_keep;
     for (int c0 = 0; c0 < nf; c0 += 1024) {
         const int i = c0 + threadIdx.x;
@@ -384,16 +386,18 @@ int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int 
     return VOFE_OK;
 }
 
-int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy, const void* d_first_xy,
-                            int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in, int n,
-                            double alpha_min, uint8_t* d_flag_out, double* d_xyz) {
+int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const VofePoseK* h_pk, const float* d_cur_xy,
+                            const void* d_first_xy, int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in,
+                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz) {
     if (n == 0) return VOFE_OK;
     const dim3 grid((n + 63) / 64), block(64);
+    VofePoseK pk;
+    if (h_pk) { pk = *h_pk; d_K = nullptr; d_pose = nullptr; } else memset(&pk, 0, sizeof(pk));
     if (first_is_f64)
-        hipLaunchKernelGGL(triangulate_kernel<double>, grid, block, 0, ctx->stream, d_K, d_pose, reinterpret_cast<const float2*>(d_cur_xy),
+        hipLaunchKernelGGL(triangulate_kernel<double>, grid, block, 0, ctx->stream, d_K, d_pose, pk, reinterpret_cast<const float2*>(d_cur_xy),
                            static_cast<const double*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
     else
-        hipLaunchKernelGGL(triangulate_kernel<float>, grid, block, 0, ctx->stream, d_K, d_pose, reinterpret_cast<const float2*>(d_cur_xy),
+        hipLaunchKernelGGL(triangulate_kernel<float>, grid, block, 0, ctx->stream, d_K, d_pose, pk, reinterpret_cast<const float2*>(d_cur_xy),
                            static_cast<const float*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "triangulate launch");
@@ -402,17 +406,19 @@ int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_po
 
 int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first_is_f64, double* d_T, int tdim, int m, int cap_c,
                                  const uint8_t* d_promote, const double* d_xyz, const float* d_features, const uint8_t* d_fmask,
-                                 int nf, const double* d_pose, float* d_P, int k, int cap_p, float* d_track_next, float* d_new_P,
-                                 double* d_new_X, int* d_counts) {
+                                 int nf, const double* d_pose, const VofePoseK* h_pk, float* d_P, int k, int cap_p, float* d_track_next,
+                                 float* d_new_P, double* d_new_X, int* d_counts) {
+    VofePoseK pk;
+    if (h_pk) { pk = *h_pk; d_pose = nullptr; } else memset(&pk, 0, sizeof(pk));
     if (first_is_f64)
         hipLaunchKernelGGL(candidate_commit_kernel<double>, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<float2*>(d_C),
                            static_cast<double*>(d_F), d_T, tdim, m, cap_c, d_promote, d_xyz, reinterpret_cast<const float2*>(d_features),
-                           d_fmask, nf, d_pose, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
+                           d_fmask, nf, d_pose, pk, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
                            reinterpret_cast<float2*>(d_new_P), d_new_X, d_counts);
     else
         hipLaunchKernelGGL(candidate_commit_kernel<float>, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<float2*>(d_C),
                            static_cast<float*>(d_F), d_T, tdim, m, cap_c, d_promote, d_xyz, reinterpret_cast<const float2*>(d_features),
-                           d_fmask, nf, d_pose, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
+                           d_fmask, nf, d_pose, pk, reinterpret_cast<float2*>(d_P), k, cap_p, reinterpret_cast<float2*>(d_track_next),
                            reinterpret_cast<float2*>(d_new_P), d_new_X, d_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "candidate_commit launch");

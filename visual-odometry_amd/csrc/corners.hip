@@ -341,9 +341,12 @@ __global__ __launch_bounds__(256) void corner_score_strip(const uint8_t* __restr
 // ckey map: score bits of candidates, 0 elsewhere.  No list is built here: the bucket scatter below
 // reads the state map.  Histogram and scatter cursors exist in N_COPY copies chosen by pixel tile,
 // which divides the same-address atomic traffic of dense buckets.
-constexpr int NMS_ROWS = 8;      // rows per thread: a 256-thread block covers 64 x 32 pixels
+// rows per thread (template parameter of nms_map): a 256-thread block covers 64 x 4*ROWS pixels.  Every row costs a
+// thread two dependent memory round trips (the score, then -- for pixels above the threshold -- the eight neighbours),
+// so a small frame takes fewer rows per thread and more waves, a large one amortises the per-wave set-up over 8 rows
+constexpr int NMS_ROWS_MAX = 8;
 constexpr int N_COPY = 1;        // measured: more copies do not speed the atomics up, they only lengthen the scan
-__device__ __forceinline__ unsigned tile_copy(int x, int y) { return (unsigned)((x >> 6) + (y >> 5)) & (N_COPY - 1); }
+__device__ __forceinline__ unsigned tile_copy(int x, int y) { return (unsigned)((x >> 6) + (y >> 5)) & (N_COPY - 1); }   // (N_COPY == 1: always 0)
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of the bucket histogram in (bucket, copy) order: one 1024-thread block per image,
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(1024) void bucket_scan(unsigned* __restrict__ hist,
                            base, full_ratio, quality, s_w, &s_n);
 }
 
+template <int NMS_ROWS>
 __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, int h, int w, double quality,
                                                GfttHdr* __restrict__ hdr, uint16_t* __restrict__ state,
                                                unsigned* __restrict__ ckey, unsigned* __restrict__ hist,
@@ -1123,9 +1127,16 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     if (rc) return rc;
     // VOFE_GFTT_CHAIN=split keeps the longer chain of round 1 (tests: both chains must give the same corners)
     const bool merged = kn.gftt_chain != 's';     // VOFE_GFTT_CHAIN=split: the last stage as three launches (tests: same corners)
-    { VOFE_TIMED(ctx, "nms_map");
-    hipLaunchKernelGGL(nms_map, dim3((w + 63) / 64, (h + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), batch), dim3(256), 0, st,
-                       score, h, w, quality, hdr, state, ckey, hist, d_mask); }
+    {
+        // rows per thread by launch size: the chip holds ~8 k waves of this kernel at once
+        const long long waves1 = (long long)((w + 63) / 64) * ((h + 3) / 4) * 4 * batch;          // at one row per thread
+        int rows = kn.nms_rows > 0 ? kn.nms_rows : (waves1 <= 8192 ? 1 : waves1 <= 16384 ? 2 : waves1 <= 32768 ? 4 : 8);
+        VOFE_TIMED(ctx, "nms_map");
+#define VOFE_NMS(R) hipLaunchKernelGGL(nms_map<R>, dim3((w + 63) / 64, (h + 4 * R - 1) / (4 * R), batch), dim3(256), 0, st, \
+                                       score, h, w, quality, hdr, state, ckey, hist, d_mask)
+        if (rows >= 8) VOFE_NMS(8); else if (rows >= 4) VOFE_NMS(4); else if (rows >= 2) VOFE_NMS(2); else VOFE_NMS(1);
+#undef VOFE_NMS
+    }
     { VOFE_TIMED(ctx, "bucket_scan");
     hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full, quality); }
     { VOFE_TIMED(ctx, "bucket_scatter");

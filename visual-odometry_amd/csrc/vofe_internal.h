@@ -30,6 +30,7 @@ struct VofeKnobs {
     bool pad_copy_generic;    // VOFE_PAD_COPY=generic: the any-width copy / border kernels
     bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
     int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
+    int nms_rows;             // VOFE_NMS_ROWS: rows per thread of the NMS kernel, 1 / 2 / 4 / 8 (0 = by launch size)
     bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
     bool gftt_debug;          // VOFE_GFTT_DEBUG
     char gftt_chain;          // VOFE_GFTT_CHAIN: 's'plit = the detector's last stage as three launches (round 1's chain)
@@ -118,13 +119,16 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
                                  int first_is_f64, const double* d_transform, int tdim, int n, double dist_min,
                                  double dist_max, double dist_tri, float* d_tracked_out, void* d_first_out,
                                  double* d_transform_out, uint8_t* d_tri_out, int* d_count_out);
-int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy, const void* d_first_xy,
-                            int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in, int n,
-                            double alpha_min, uint8_t* d_flag_out, double* d_xyz);
+// current pose (3x4) and intrinsics (3x3) handed to a kernel by value: h_pk non-NULL replaces the device pointers
+// d_K / d_pose (no upload, nothing to wait for)
+struct VofePoseK { double pose[12]; double K[9]; };
+int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const VofePoseK* h_pk, const float* d_cur_xy,
+                            const void* d_first_xy, int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in,
+                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz);
 int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first_is_f64, double* d_T, int tdim, int m, int cap_c,
                                  const uint8_t* d_promote, const double* d_xyz, const float* d_features, const uint8_t* d_fmask,
-                                 int nf, const double* d_pose, float* d_P, int k, int cap_p, float* d_track_next, float* d_new_P,
-                                 double* d_new_X, int* d_counts);
+                                 int nf, const double* d_pose, const VofePoseK* h_pk, float* d_P, int k, int cap_p, float* d_track_next,
+                                 float* d_new_P, double* d_new_X, int* d_counts);
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
