@@ -540,7 +540,38 @@ def pcie_inclusive(fe, frames, pts, H, W, n):
     for i in range(reps):
         fe.goodFeaturesToTrack(frames[i % nf], n, 0.01, 7)
     det = (time.perf_counter() - t0) / reps
+    # the reference's whole per-frame front end (continuous.py:86-92 landmark tracking + :375-495 _handle_candidates) on
+    # the native frame-state object: numpy frame in, landmark positions out, pose + inlier mask in; the reference's
+    # own settings (1000 corners / 10 px), 300 landmarks + 700 candidates at the start
+    from visual_odometry_amd import DeviceFrameState
+    first = fe.goodFeaturesToTrack(frames[0], 1000, 0.01, 10).reshape(-1, 2)
+    P0, C0 = first[:300].T.copy(), first[300:].T.copy()
+    X0 = np.random.default_rng(1).normal(0, 5, (3, P0.shape[1])) + [[0], [0], [20]]
+
+    def pose_at(t):
+        T = np.eye(4)
+        T[:3, 3] = [0.02 * t, 0.0, 0.6 * t]
+        return T
+    T0 = np.tile(pose_at(0)[:3, :].reshape(-1, 1), (1, C0.shape[1]))
+    st = DeviceFrameState(H, W, np.array([[718.856, 0, 607.19], [0, 718.856, 185.2], [0, 0, 1.0]]), winSize=WIN, maxLevel=MAX_LEVEL,
+                          criteria=CRITERIA, minEigThreshold=MIN_EIG, max_corners=1000, quality_level=0.01, min_distance=10)
+    t_fs, n_fs = 0.0, 0
+    for r in range(13):
+        st.reset(frames[0], P0, X0, C0, C0.astype(np.float64), T0)
+        t0 = time.perf_counter()
+        for t in range(1, nf):
+            _, status = st.track(frames[t])
+            st.update(pose_at(t), status == 1)
+        if r:
+            t_fs += time.perf_counter() - t0
+            n_fs += nf - 1
+    st.close()
+    fs_frame = t_fs / n_fs
     return {"track_keypoints_us": round(per_call * 1e6, 1), "track_keypoints_frames_per_s": round(1.0 / per_call, 1),
+            "front_end_frame_us": round(fs_frame * 1e6, 1), "front_end_frames_per_s": round(1.0 / fs_frame, 1),
+            "front_end_frame": "vofe_framestate (track + update): landmark tracking, candidate tracking, detection (1000 corners, 10 px), "
+                               "compaction, de-duplication, triangulation, promotion, append; %d landmarks + %d candidates at the start" % (
+                                   P0.shape[1], C0.shape[1]),
             "sequence_tracker_track_us": round(cached * 1e6, 1), "sequence_tracker_frames_per_s": round(1.0 / cached, 1),
             "goodFeaturesToTrack_us": round(det * 1e6, 1),
             "note": "serial calls with numpy in / numpy out through frontend.py: track_keypoints uploads both 1241x376 frames "
