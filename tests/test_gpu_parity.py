@@ -175,13 +175,13 @@ def test_lk_21x21_generic_kernel_path(fe, knob):
 
 
 @pytest.mark.parametrize("win", [11, 31])
-@pytest.mark.parametrize("kernel", ["default", "generic"])
+@pytest.mark.parametrize("kernel", ["default", "x1", "lp", "generic"])
 def test_lk_ragged_compile_time_windows(fe, knob, win, kernel):
     """11x11 (the reference's Parking window) and 31x31 run compile-time-geometry kernels whose last row group is
     ragged (3+3+3+2 and 16+15 rows); the run-time-geometry kernel (VOFE_LK=generic) must agree with them and the
     oracle on tracking, flags, wild points, flat frames and extreme contrast."""
-    if kernel == "generic":
-        knob("VOFE_LK", "generic")
+    if kernel != "default":
+        knob("VOFE_LK", kernel)       # (default: the size rule -- level-parallel for 11x11 at this point count; "lp" has no 31x31 form)
     a, b = _seq(240, 320, 21)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 21)
     for lvl in (3, 0):
@@ -209,14 +209,16 @@ def test_lk_ragged_compile_time_windows(fe, knob, win, kernel):
     assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
 
 
-@pytest.mark.parametrize("ppw", ["x2", "x4"])
-def test_lk_several_keypoints_per_wavefront_kernel(fe, knob, ppw):
-    """Large 21x21 launches take the kernel that packs several keypoints into one wavefront; forced here on
-    small inputs: counts not divisible by the packing, wild points, flags, extreme contrast, FB twin."""
+@pytest.mark.parametrize("ppw", ["x1", "lp", "x2", "x4"])
+def test_lk_21x21_kernel_families(fe, knob, ppw):
+    """The 21x21 kernel families, each forced on the same small inputs: one keypoint per wavefront (x1), one wavefront
+    per pyramid level (lp: what small launches take by the size rule), several keypoints per wavefront (x2 / x4: what
+    large launches take): counts not divisible by the packing, every level count, wild points, flags, extreme
+    contrast, FB twin."""
     knob("VOFE_LK", ppw)
     a, b = _seq(240, 320, 12)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 401, 0.01, 7), 401, 240, 320, 12)
-    for lvl in (3, 0):
+    for lvl in (3, 2, 1, 0):
         exact, _, st = _lk_compare(fe, a, b, pts, (21, 21), lvl)
         assert exact and st.sum() > 200
     init = (pts + np.float32([1.0, 0.5])).astype(np.float32)
@@ -1188,7 +1190,7 @@ def test_randomised_lk_21x21_sweep_all_kernels(fe, knob):
         with np.errstate(all="ignore"):
             n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig, nthreads=8)
             t0 = oracle.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig, 1.0, 8)
-        for kern in ("x1", "x2", "x4"):
+        for kern in ("x1", "lp", "x2", "x4"):
             knob("VOFE_LK", kern)
             n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig)
             assert np.array_equal(s0, s1), (case, kern, h, w, lvl)

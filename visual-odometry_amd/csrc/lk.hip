@@ -216,6 +216,9 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
     }
 }
 
+// one wave per level pays while the extra waves find idle SIMDs: measured (tools/lp_sweep.sh, KITTI / Parking frames, fwd + bwd)
+// 300 points 38.2 -> 34.5 us, 500 points 39.2 -> 35.8 us, break-even near 1000 points (4 waves per SIMD), 30 % slower at 2000
+constexpr int LK_LP_MAX_POINTS = 640;
 constexpr int LK_X2_MIN_POINTS = 4000;     // measured (scratch/lk_threshold.py, lk_bench.py): one per wavefront 5 % ahead at 3000 points, two per wavefront 8 % ahead at 4000
 constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
 
@@ -490,6 +493,286 @@ __global__ __launch_bounds__(64) void lk_track_kernel(LKArgs a) {
             st_acc[7] = (unsigned)(__builtin_amdgcn_s_memtime() - st_wave0);            // whole wavefront
             if (blockIdx.x < 256) for (int k = 0; k < STAMP_N; ++k) a.counters[8 + STAMP_N * blockIdx.x + k] = st_acc[k];
 #endif
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level-parallel kernel for SMALL launches (the reference's real load: a few hundred landmarks and candidates per frame).
+// Such a launch leaves most SIMDs with one wavefront or none, and lasts as long as one keypoint's dependent chain:
+// 2 directions x n_levels x (template set-up + Gauss-Newton iterations).  Only the iterations depend on the coarser
+// level's result; the template window, the structure tensor and the minimum-eigenvalue test of a level depend on the
+// fixed previous point alone.  So a keypoint gets one wavefront PER LEVEL (a workgroup of n_levels waves): all levels'
+// set-ups run at the same time, then the levels iterate in turn, coarse to fine, handing the position over through
+// LDS (one workgroup barrier per level).  The chain per direction shrinks from n_levels set-ups + iterations to one
+// set-up + iterations.  Each wave also stages a search region ahead of time around where the walk will most likely
+// start (forward: zero flow; backward: the original point, where a successful track must return to); the region is a
+// cache of pixel pairs, a wrong guess only costs the re-staging the iteration loop does anyway.  Arithmetic per level
+// is lk_one's, statement for statement, so results are bit-identical.  Compile-time windows only (21x21, 11x11).
+__device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+constexpr int LK_LP_MAX_LEVELS = 4;
+constexpr int LK_LP_HAND = 16;              // LDS words in front of the regions: hand-over position, status
+
+template <int R, int WC>
+__device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
+                                          int slotA, int slotB, float px, float py, float gx, float gy, float& outx, float& outy,
+                                          int& status, float& err, int flags, unsigned* lds, float* hand, int level, int lane,
+                                          int x, int y0, int ny, unsigned& n_lv, unsigned& n_it) {
+    constexpr bool REG = WC % R == 0;
+    constexpr bool WIDE = WC == 21;
+    constexpr int w = WC, h = WC;
+    const float hx = (float)(w - 1) * 0.5f, hy = (float)(h - 1) * 0.5f;
+    const int top = a.n_levels - 1;
+    constexpr int segs = (WC + 1 + 2 * LK_MARGIN + 7) / 8, rs = 8 * segs;
+    constexpr int inv_segs = (1 << 20) / segs + 1;
+    constexpr int tasks = (WC + 1 + 2 * LK_MARGIN) * segs;
+#define LK_ROW(r) (REG ? (r) : min((r), ny))
+    // ---- this level's fixed part (all levels at once) ----------------------------------------------------------
+    const VofeLevel A = LA[level];
+    const VofeLevel B = LB[level];
+    const float sc = 1.0f / (float)(1 << level);
+    float ppx = px * sc, ppy = py * sc;
+    const float tpx = ppx, tpy = ppy;                 // the walk's start at the top level
+    ppx -= hx; ppy -= hy;
+    const int ipx = floor_i(ppx), ipy = floor_i(ppy);
+    const bool in_bounds = !(ipx < -w || ipx >= A.w || ipy < -h || ipy >= A.h);
+    const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
+    bool staged = false, eig_ok = false;
+    int rx0 = 0, ry0 = 0;
+    int Ival[R], Dval[R];
+    float A11 = 0.f, A12 = 0.f, A22 = 0.f, Dd = 0.f;
+    if (in_bounds) {
+        StageRegs pre;
+        {
+            const int sx = floor_i(gx * sc - hx), sy = floor_i(gy * sc - hy);
+            if (!(sx < -w || sx >= B.w || sy < -h || sy >= B.h)) {
+                rx0 = sx - LK_MARGIN; ry0 = sy - LK_MARGIN;
+                staged = true;
+            }
+        }
+        float fA11, fA12, fA22;
+        {
+            const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
+            const long long base = (long long)slotA * A.slot_stride + (long long)ipy * A.pitch + ipx;
+            const gbase_t Ib = (gbase_t)(A.I + base);
+            const gbase_t Db = (gbase_t)(A.D + base);
+            const unsigned off0 = (unsigned)(y0 * A.pitch + x);
+            unsigned pI[R + 1];
+            unsigned pX[R + 1], pY[R + 1];
+            if (staged) stage_load<WIDE>(pre, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+#pragma unroll
+            for (int r = 0; r <= R; ++r) {
+                const unsigned off = off0 + (unsigned)(LK_ROW(r) * A.pitch);
+                const unsigned two = gload_u16(Ib, off);
+                const uint2 dd = gload_u64(Db, off * 4u);
+                pI[r] = __builtin_amdgcn_perm(0u, two, 0x0c010c00u);
+                pX[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
+                pY[r] = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
+            }
+            int a11 = 0, a12 = 0, a22 = 0;
+            const unsigned dw0 = (REG && ny == 0) ? 0u : q.w0, dw1 = (REG && ny == 0) ? 0u : q.w1;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
+                int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
+                int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                if (!REG && k >= ny) { ix = 0; iy = 0; }
+                Ival[k] = iv;
+                Dval[k] = (ix & 0xffff) | (iy << 16);
+                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+            }
+            if (partials_fit(a11, a12, a22)) {
+                fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
+            } else {
+                fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
+            }
+        }
+        const float FLT_SCALE0 = 1.f / (float)(1 << 20);
+        A11 = fA11 * FLT_SCALE0; A12 = fA12 * FLT_SCALE0; A22 = fA22 * FLT_SCALE0;
+        Dd = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
+        eig_ok = !(minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f);
+        Dd = 1.f / Dd;
+        if (staged) {                                  // (uniform) the region guessed above; this wave's reads of the other direction are done
+            wave_lds_order();
+            stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
+            stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 64 * ST_BATCH, lane);
+            wave_lds_order();
+        }
+    }
+    // ---- the levels in turn, coarse to fine ----------------------------------------------------------------------
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    for (int s = top; s >= 0; --s) {
+        if (s == level) {
+            float npx, npy;
+            if (level == top) {
+                if (flags & 4) { npx = outx * sc; npy = outy * sc; }
+                else { npx = tpx; npy = tpy; }
+            } else { npx = hand[0] * 2.f; npy = hand[1] * 2.f; }
+            float ox = npx, oy = npy;
+            if (!in_bounds) {
+                if (level == 0) { status = 0; err = 0.f; }
+            } else {
+                ++n_lv;
+                if (!eig_ok) {
+                    if (level == 0) status = 0;
+                } else {
+                    npx -= hx; npy -= hy;
+                    float pdx = 0.f, pdy = 0.f;
+                    bool lost = false;
+                    for (int j = 0; j < a.max_count; ++j) {
+                        const int inx = floor_i(npx), iny = floor_i(npy);
+                        if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                            if (level == 0) status = 0;
+                            lost = true;
+                            break;
+                        }
+                        if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                            wave_lds_order();
+                            rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                            stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                            staged = true;
+                            wave_lds_order();
+                        }
+                        ++n_it;
+                        const Wts q = bilinear_weights(npx, npy, inx, iny);
+                        const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
+                        unsigned P[R + 1];
+#pragma unroll
+                        for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
+                        int b1 = 0, b2 = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
+                            const int diff = jv - Ival[k];
+                            b1 += diff * (int)(short)Dval[k];
+                            b2 += diff * (Dval[k] >> 16);
+                        }
+                        float fb1, fb2;
+                        if (partials_fit(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
+                        else { fb1 = wave_sum_to_float(b1); fb2 = wave_sum_to_float(b2); }
+                        fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
+                        const float dx = (A12 * fb2 - A22 * fb1) * Dd;
+                        const float dy = (A12 * fb1 - A11 * fb2) * Dd;
+                        npx += dx; npy += dy;
+                        ox = npx + hx; oy = npy + hy;
+                        const float d2 = dx * dx + dy * dy;
+                        bool conv = d2 < a.eps2_lo;
+                        if (__any(!conv && !(d2 > a.eps2_hi)))
+                            conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.eps2;
+                        if (conv) break;
+                        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                            ox -= dx * 0.5f; oy -= dy * 0.5f;
+                            break;
+                        }
+                        pdx = dx; pdy = dy;
+                    }
+                    (void)lost;
+                    if (status && level == 0 && !(flags & LK_NO_ERR)) {
+                        const float ex = ox - hx, ey = oy - hy;
+                        const int inx = floor_i(ex), iny = floor_i(ey);
+                        if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                            status = 0;
+                        } else {
+                            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                                wave_lds_order();
+                                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                                stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                                staged = true;
+                                wave_lds_order();
+                            }
+                            const Wts q = bilinear_weights(ex, ey, inx, iny);
+                            const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
+                            unsigned P[R + 1];
+#pragma unroll
+                            for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
+                            int se = 0;
+#pragma unroll
+                            for (int k = 0; k < R; ++k) {
+                                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
+                                const int diff = jv - Ival[k];
+                                se += (REG || k < ny) ? abs(diff) : 0;
+                            }
+                            if (REG && ny == 0) se = 0;
+                            err = wave_sum_to_float(se) / (float)(32 * w * h);
+                        }
+                    }
+                }
+            }
+            outx = ox; outy = oy;
+            if (lane == 0) {
+                hand[0] = ox; hand[1] = oy;
+                if (level == 0) hand[2] = status ? 1.f : 0.f;
+            }
+        }
+        __syncthreads();          // every wave of the keypoint, every level: the hand-over
+    }
+#undef LK_ROW
+}
+
+template <int R, int WC>
+__global__ __launch_bounds__(64 * LK_LP_MAX_LEVELS) void lk_track_kernel_lp(LKArgs a) {
+    extern __shared__ unsigned lds[];
+    constexpr int REGION = (WC + 1 + 2 * LK_MARGIN) * 8 * ((WC + 1 + 2 * LK_MARGIN + 7) / 8);
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, level = threadIdx.x >> 6;      // one wave per pyramid level (blockDim = 64 * n_levels)
+    float* hand = reinterpret_cast<float*>(lds);
+    unsigned* region = lds + LK_LP_HAND + level * REGION;
+    const int g = lane / WC;
+    const int x = lane - g * WC;
+    constexpr bool REG = WC % R == 0;
+    const bool active = g < (WC + R - 1) / R;
+    const int y0 = REG ? (active ? g * R : 0) : min(g * R, WC);
+    const int ny = REG ? (active ? R : 0) : (active ? min(R, WC - y0) : 0);
+
+    const float2 p = a.prev_pts[i];
+    int idx = a.img_idx ? a.img_idx[i] : 0;
+    const bool bad_idx = (unsigned)idx >= (unsigned)a.n_images;      // block-uniform
+    if (bad_idx) idx = 0;
+    float fx = 0.f, fy = 0.f;
+    if (a.flags & 4) { const float2 q = a.next_pts[i]; fx = q.x; fy = q.y; }
+    int st = bad_idx ? 0 : 1;
+    float er = 0.f;
+    float bx = 0.f, by = 0.f;
+    const int ndir = bad_idx ? 0 : (a.fb ? 2 : 1);
+    unsigned n_lv = 0, n_it = 0;
+    for (int dir = 0; dir < ndir; ++dir) {
+        const VofeLevel* LA = dir ? a.lv_b : a.lv_a;
+        const VofeLevel* LB = dir ? a.lv_a : a.lv_b;
+        const int sa = (dir ? a.slot_b : a.slot_a) + idx, sb = (dir ? a.slot_a : a.slot_b) + idx;
+        const float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
+        // where the walk is expected to start at level 0: the initial guess going forward, the original point coming back
+        const float gx = dir ? p.x : ((a.flags & 4) ? fx : p.x), gy = dir ? p.y : ((a.flags & 4) ? fy : p.y);
+        float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
+        int s = 1;
+        lk_lp_dir<R, WC>(a, LA, LB, sa, sb, qx, qy, gx, gy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, hand, level, lane, x, y0,
+                         ny, n_lv, n_it);
+        // the level-0 wave left the result in the hand-over words (its barrier has passed): every wave takes it from there
+        const float rx = hand[0], ry = hand[1];
+        const int rs_ = hand[2] != 0.f ? 1 : 0;
+        if (dir == 0) { fx = rx; fy = ry; st = rs_; er = e; }
+        else { bx = rx; by = ry; }
+        __syncthreads();                      // hand-over words read by all before the next direction rewrites them
+        if (!st) break;                       // block-uniform
+    }
+    if (a.fb) {
+        const float dx = fabsf(p.x - bx), dy = fabsf(p.y - by);
+        float d = dx > dy ? dx : dy;
+        if (dx != dx || dy != dy) d = __builtin_nanf("");
+        st = st & (d < a.fb_thresh ? 1 : 0);
+    }
+    if (bad_idx) { st = 0; er = 0.f; }
+    if (lane == 0) {
+        if (level == 0) {
+            a.next_pts[i] = make_float2(fx, fy);
+            a.status[i] = (uint8_t)st;
+            a.err[i] = er;
+        }
+        if (a.counters) {
+            if (level == 0) atomicAdd(a.counters + 0, 1ull);
+            atomicAdd(a.counters + 1, (unsigned long long)n_lv);
+            atomicAdd(a.counters + 2, (unsigned long long)n_it);
         }
     }
 }
@@ -877,10 +1160,19 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     const unsigned long long span_a = (unsigned long long)prev->slots * (unsigned long long)prev->lv[0].slot_stride * 4ull;
     const unsigned long long span_b = (unsigned long long)next->slots * (unsigned long long)next->lv[0].slot_stride * 4ull;
     const bool x2_ok = a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g') && span_a < 0xf0000000ull && span_b < 0xf0000000ull;
+    // small launches of the reference's two windows: one wavefront per pyramid level ("lp" forces it for any point count;
+    // not with OPTFLOW_LK_GET_MIN_EIGENVALS, whose err output follows the levels in order)
+    const bool lp_ok = a.win_w == a.win_h && (a.win_w == 21 || a.win_w == 11) && a.n_levels >= 2 && a.n_levels <= LK_LP_MAX_LEVELS &&
+                       !(flags & 8) && !(force && force[0] != 'l');
+    const size_t lp_lds = ((size_t)LK_LP_HAND + (size_t)a.n_levels * a.rs * a.rh) * 4;
     if (x2_ok && force && force[0] == 'x' && force[1] == '4')
         hipLaunchKernelGGL(lk_track_kernel_x2<4>, dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
     else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
         hipLaunchKernelGGL(lk_track_kernel_x2<2>, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+    else if (lp_ok && a.win_w == 21 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
+        hipLaunchKernelGGL((lk_track_kernel_lp<7, 21>), dim3(a.n), dim3(64 * a.n_levels), lp_lds, st, a);
+    else if (lp_ok && a.win_w == 11 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
+        hipLaunchKernelGGL((lk_track_kernel_lp<3, 11>), dim3(a.n), dim3(64 * a.n_levels), lp_lds, st, a);
     else if (a.win_w == 21 && a.win_h == 21 && !(force && force[0] == 'g')) launch_r<7, 21>(a, lds_bytes, st);
     // the other windows the reference uses (constants.py:49 Parking 11x11) and the stress configuration's 31x31:
     // compile-time geometry with a ragged last row group (4 x 3 rows for 11, 16 + 15 rows for 31)
