@@ -291,7 +291,9 @@ int vofe_framestate_update(vofe_framestate* fs, const double* h_pose, const uint
 int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep);
 int vofe_framestate_wait(vofe_framestate* fs, int* n_promoted);
 int vofe_framestate_counts(vofe_framestate* fs, int* n_landmarks, int* n_candidates);
-/* World points (K,3) f64 of the current landmarks, in landmark order (pointer valid until the next update/reset). */
+/* World points (K,3) f64 of the current landmarks, in landmark order (pointer valid until the next update/reset).
+ * Between track and update these are the landmarks track started from, row for row the points it returned: what the
+ * pose estimation pairs the tracked image points with (continuous.py:95-101). */
 int vofe_framestate_landmarks_world(vofe_framestate* fs, const double** h_xyz, int* n_landmarks);
 /* The FrameState arrays as the reference holds them (any pointer may be NULL); synchronous; not between track and update. */
 int vofe_framestate_download(vofe_framestate* fs, float* h_landmarks_xy, float* h_cand_xy, void* h_first_xy,

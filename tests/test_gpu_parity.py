@@ -991,6 +991,8 @@ def test_device_resident_frame_state_follows_the_reference_frame_loop(fe):
         rt, rs, _ = oracle.track_keypoints(Pi, frames[t - 1], frames[t], nthreads=8)
         gt, gs = st.track(frames[t])
         assert gt.dtype == np.float32 and np.array_equal(gt, rt) and np.array_equal(gs, rs), t
+        Xw = st.landmarks_world                                  # between the phases: the world points PnP pairs with `gt`
+        assert Xw.shape == Xi.shape and np.allclose(Xw, Xi, rtol=1e-6, atol=1e-6), t
         keep = rs == 1
         keep[::7] = False                                        # stand-in for the RANSAC inlier mask (continuous.py:95-101)
         Pi, Xi = rt[:, keep], Xi[:, keep]

@@ -374,8 +374,7 @@ int vofe_framestate_counts(vofe_framestate* fs, int* n_landmarks, int* n_candida
 
 int vofe_framestate_landmarks_world(vofe_framestate* fs, const double** h_xyz, int* n_landmarks) {
     if (!fs || !h_xyz || !n_landmarks) { vofe_set_error("vofe_framestate_landmarks_world: NULL argument"); return VOFE_E_ARG; }
-    if (fs->phase == 1) { vofe_set_error("vofe_framestate_landmarks_world between track and update"); return VOFE_E_ARG; }
-    int rc0 = collect_update(fs);
+    int rc0 = collect_update(fs);          // (between track and update the array is the one track started from: what PnP pairs the tracked points with)
     if (rc0) return rc0;
     *h_xyz = fs->world;
     *n_landmarks = fs->K;

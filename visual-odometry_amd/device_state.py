@@ -104,8 +104,8 @@ class DeviceFrameState:
 
     def download(self):
         """The FrameState arrays as the reference holds them: (Pi (2,K) f32, Xi (3,K) f64, Ci (2,M) f32, Fi (2,M), Ti (12,M) f64)."""
-        X = self.landmarks_world                  # raises between track() and update()
-        k, m = self.K, self.M
+        k, m = self.K, self.M                     # raises between track() and update()
+        X = self.landmarks_world
         P, Cc = np.empty((k, 2), np.float32), np.empty((m, 2), np.float32)
         Fc, Tc = np.empty((m, 2), self.fdt), np.empty((m, 12), np.float64)
         _lib.check(self.L.vofe_framestate_download(self._h, P.ctypes.data, Cc.ctypes.data, Fc.ctypes.data, Tc.ctypes.data))
