@@ -113,6 +113,7 @@ class FrontEnd:
         _lib.check(self.L.vofe_create(int(device), C.c_void_p(self.stream.cuda_stream), C.byref(self.ctx)))
         self._pyr_cache = {}
         self._map_buf, self._map_dev, self._map_ok = None, None, None
+        self._stage_cache, self._stage_busy = {}, False
         # close before interpreter teardown (HIP objects must not be freed after the runtime is gone)
         self._fin = weakref.finalize(self, FrontEnd._finalize, self.L, self.ctx, self._pyr_cache)
 
@@ -130,13 +131,16 @@ class FrontEnd:
 
     def synchronize(self):
         _lib.check(self.L.vofe_synchronize(self.ctx))
+        self._stage_busy = False
 
     def reload_env(self):
         """Re-read the VOFE_* switches (the library reads them once, at vofe_create).  Test aid."""
         _lib.check(self.L.vofe_reload_env(self.ctx))
 
     # -------------------------------------------------------------------------------- helpers
-    def to_device(self, img):
+    def to_device(self, img, tag=0):
+        """Device copy of a frame.  A host array comes back as a view of a cached device buffer (per shape and `tag`) that
+        the next to_device / upload_frames call of that shape and tag overwrites: use it before uploading another."""
         if isinstance(img, torch.Tensor):
             if img.dtype != torch.uint8 or img.dim() != 2:
                 raise error(-1, "image must be a single-channel 8-bit (H,W) array")
@@ -144,7 +148,38 @@ class FrontEnd:
         a = np.asarray(img)
         if a.dtype != np.uint8 or a.ndim != 2:
             raise error(-1, "image must be a single-channel 8-bit (H,W) array")
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=False)
+        return self.upload_frames(a, tag=tag)[0]
+
+    def upload_frames(self, *imgs, out=None, tag=0):
+        """Host frames -> one (k,H,W) device tensor through a cached pinned staging buffer and ONE asynchronous copy on
+        the context's stream (a pageable torch copy per frame costs ~30 us and a torch.stack launch on top; this is
+        ~7 us of host memcpy per frame and one ~15-25 us copy command).  The returned tensor is cached per (k,H,W) and
+        overwritten by the next call of the same shape unless `out` (a device tensor of that shape) is given; the
+        staging buffer is reused once the caller has synchronised, which every cv2-shaped call does before returning."""
+        arrs = []
+        for img in imgs:
+            a = np.asarray(img)
+            if a.dtype != np.uint8 or a.ndim != 2:
+                raise error(-1, "image must be a single-channel 8-bit (H,W) array")
+            arrs.append(a)
+        if any(a.shape != arrs[0].shape for a in arrs):
+            raise error(-1, "images must have the same size")
+        key = (tag, len(arrs)) + arrs[0].shape          # `tag` keeps apart buffers that are alive at the same time (image / mask)
+        ent = self._stage_cache.get(key)
+        if ent is None:
+            ent = (torch.empty(key[1:], dtype=torch.uint8).pin_memory(), torch.empty(key[1:], dtype=torch.uint8, device=self.device))
+            self._stage_cache[key] = ent
+        stage, dev = ent
+        if self._stage_busy:                      # an upload whose consumer did not synchronise (SequenceTracker.prefetch-style use)
+            self.synchronize()
+        hs = stage.numpy()
+        for i, a in enumerate(arrs):
+            hs[i][...] = a
+        dst = dev if out is None else out
+        with torch.cuda.stream(self.stream):
+            dst.copy_(stage, non_blocking=True)
+        self._stage_busy = True
+        return dst
 
     def pyramid(self, slots, height, width, winSize, maxLevel):
         key = (int(slots), int(height), int(width), int(winSize[0]), int(winSize[1]), int(maxLevel))
@@ -218,15 +253,13 @@ class FrontEnd:
     # -------------------------------------------------------------------------------- cv2 twins
     def calcOpticalFlowPyrLK(self, prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
                              criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
-        a, b = self.to_device(prevImg), self.to_device(nextImg)
-        if a.shape != b.shape:
-            raise error(-1, "prevImg and nextImg must have the same size")
         p = self._points(prevPts)
         n = p.shape[0]
+        pair = self._frame_pair(prevImg, nextImg, "prevImg and nextImg must have the same size")
         if n == 0:
             return None, None, None
-        pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
-        pyr.build(torch.stack([a, b]), 0)
+        pyr = self.pyramid(2, pair.shape[1], pair.shape[2], winSize, maxLevel)
+        pyr.build(pair, 0)
         d_prev = torch.from_numpy(p).to(self.device)
         buf, d_next, d_err, d_st = self._packed_outputs(n)
         if flags & OPTFLOW_USE_INITIAL_FLOW:
@@ -238,7 +271,20 @@ class FrontEnd:
                                         d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
                                         float(criteria[2]), int(flags), float(minEigThreshold)))
         nxt, st, err = self._unpack_outputs(buf, n)
+        self._stage_busy = False                  # the blocking download above is behind the frame upload on the same stream
         return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
+
+    def _frame_pair(self, img_a, img_b, msg):
+        """(2,H,W) device tensor of two frames: host arrays travel together through the staging buffer."""
+        if isinstance(img_a, torch.Tensor) or isinstance(img_b, torch.Tensor):
+            a, b = self.to_device(img_a), self.to_device(img_b)
+            if a.shape != b.shape:
+                raise error(-1, msg)
+            return torch.stack([a, b])
+        a, b = np.asarray(img_a), np.asarray(img_b)
+        if a.ndim == 2 and b.ndim == 2 and a.dtype == np.uint8 and b.dtype == np.uint8 and a.shape != b.shape:
+            raise error(-1, msg)
+        return self.upload_frames(a, b)
 
     def track_keypoints(self, prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,
                         criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3, fb_thresh=1.0):
@@ -246,13 +292,11 @@ class FrontEnd:
         prev_keypoints = np.asarray(prev_keypoints)
         if prev_keypoints.size == 0:                                   # continuous.py:131-132
             return np.empty((2, 0)), np.empty((0,), dtype=np.uint8), np.empty((0,), dtype=np.float32)
-        a, b = self.to_device(img_prev), self.to_device(img_current)
-        if a.shape != b.shape:
-            raise error(-1, "img_prev and img_current must have the same size")
+        pair = self._frame_pair(img_prev, img_current, "img_prev and img_current must have the same size")
         p = np.ascontiguousarray(prev_keypoints.T.reshape(-1, 2).astype(np.float32))      # continuous.py:134-135
         n = p.shape[0]
-        pyr = self.pyramid(2, a.shape[0], a.shape[1], winSize, maxLevel)
-        pyr.build(torch.stack([a, b]), 0)
+        pyr = self.pyramid(2, pair.shape[1], pair.shape[2], winSize, maxLevel)
+        pyr.build(pair, 0)
         io = self._points_io(p)
         _lib.check(self.L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, io["prev"], None, 1, io["next"], io["status"], io["err"],
                                         n, int(criteria[0]), int(criteria[1]), float(criteria[2]), float(minEigThreshold),
@@ -275,7 +319,7 @@ class FrontEnd:
         cap = int(maxCorners) if maxCorners > 0 else h * w
         d_mask = None
         if mask is not None:
-            d_mask = self.to_device(mask).contiguous()
+            d_mask = self.to_device(mask, tag="mask").contiguous()
             if d_mask.shape != a.shape:
                 raise error(-1, "mask must be 8-bit and match the image size")
         out = torch.empty((max(cap, 1), 2), dtype=torch.float32, device=self.device)

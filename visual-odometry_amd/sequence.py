@@ -32,6 +32,7 @@ class SequenceTracker:
         self._img = [None, None]                  # device images of the two slots (for detect())
         self._stage, self._stage_k, self._copy_stream, self._prefetched = None, 0, None, None
         self._det_fe, self._det_stream = None, None            # side context for track_and_detect()
+        self._ring = None                          # device copies of the two newest host frames
 
     # -- frames ----------------------------------------------------------------------------------
     def prefetch(self, img_next):
@@ -68,10 +69,21 @@ class SequenceTracker:
             if self._det_stream is not None:
                 d.record_stream(self._det_stream)
             self._uploaded = pre[2]
-        else:
+        elif isinstance(img, torch.Tensor):
             d = self.fe.to_device(img)
             self._uploaded = torch.cuda.Event()                # the frame is resident once this has passed
-            self._uploaded.record(torch.cuda.current_stream(self.fe.device))
+            self._uploaded.record(self.fe.stream)
+        else:
+            # host frame: through the front end's pinned staging buffer into this tracker's own two-frame ring (the
+            # frame of either slot stays valid for detect() until the slot is reused)
+            if self._ring is None:
+                self._ring = torch.empty((2, 1, self.h, self.w), dtype=torch.uint8, device=self.fe.device)
+            a = np.asarray(img)
+            if a.shape != (self.h, self.w):
+                raise error(-1, "frame size %s does not match the tracker geometry %s" % (tuple(a.shape), (self.h, self.w)))
+            d = self.fe.upload_frames(a, out=self._ring[(self.frame_index + 1) & 1])[0]
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record(self.fe.stream)
         if tuple(d.shape) != (self.h, self.w):
             raise error(-1, "frame size %s does not match the tracker geometry %s" % (tuple(d.shape), (self.h, self.w)))
         self.frame_index += 1
