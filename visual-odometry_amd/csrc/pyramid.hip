@@ -111,11 +111,23 @@ __global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, in
     unsigned acc[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 128;
+    // all fourteen loads first: with the REFLECT_101 row index (a loop with branches) between them the loads of the seven
+    // rows went out one row per memory round trip and the kernel was bound by that latency (22.5 us per 128 frames)
+    int ry[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ry[k] = vofe_reflect101(2 * Y0 - 2 + k, S.h);
+    U4 ra[7];
+    U2 rb[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const uint8_t* r = sp + (long long)vofe_reflect101(2 * Y0 - 2 + k, S.h) * S.pitch;
-        const U4 a = *reinterpret_cast<const U4*>(r);
-        const U2 b = *reinterpret_cast<const U2*>(r + 16);
+        const uint8_t* r = sp + (long long)ry[k] * S.pitch;
+        ra[k] = *reinterpret_cast<const U4*>(r);
+        rb[k] = *reinterpret_cast<const U2*>(r + 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const U4 a = ra[k];
+        const U2 b = rb[k];
         const unsigned wv[6] = {a.a, a.b, a.c, a.d, b.a, b.b};
         unsigned win[10];                          // win[m] = bytes 2+2m .. 5+2m of the row segment
 #pragma unroll
@@ -152,13 +164,36 @@ __global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, in
             *reinterpret_cast<uint2*>(drow + X0) = q;
         }
         if (edge) {
+            // Nearly every wavefront holds a thread at a row end (a 621-pixel row is 78 groups), so this path is as hot as
+            // the body: keep it to a handful of instructions.  Left end: columns 1 and 2 go to -1 and -2.  Right end:
+            // columns w-2 and w-3 go to w and w+1 (each is picked out of the owning group's eight outputs by a select
+            // chain).  A ragged last group stores its w - X0 valid bytes as 4 + 2 + 1.
+            if (X0 == 0) {
+                if (1 < w) drow[-1] = (uint8_t)out[1];
+                if (2 < w) drow[-2] = (uint8_t)out[2];
+            }
+            const int j2 = w - 2 - X0, j3 = w - 3 - X0;
+            unsigned v2 = out[0], v3 = out[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int x = X0 + j;
-                if (x >= w) continue;
-                if (!full) drow[x] = (uint8_t)out[j];
-                if (x == 1 || x == 2) drow[-x] = (uint8_t)out[j];
-                if (x == w - 2 || x == w - 3) drow[2 * (w - 1) - x] = (uint8_t)out[j];
+            for (int j = 1; j < 8; ++j) { v2 = j2 == j ? out[j] : v2; v3 = j3 == j ? out[j] : v3; }
+            if ((unsigned)j2 < 8u) drow[w] = (uint8_t)v2;
+            if ((unsigned)j3 < 8u) drow[w + 1] = (uint8_t)v3;
+            if (!full && X0 < w) {
+                const int nv = w - X0;                                                // 1..7
+                uint8_t* dp = drow + X0;
+                int o0 = 0;
+                if (nv & 4) { *reinterpret_cast<unsigned*>(dp) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o0 = 4; }
+                if (nv & 2) {
+                    const unsigned lo = o0 ? out[4] : out[0], hi = o0 ? out[5] : out[1];
+                    *reinterpret_cast<unsigned short*>(dp + o0) = (unsigned short)(lo | (hi << 8));
+                }
+                if (nv & 1) {
+                    const int jb = nv - 1;
+                    unsigned vb = out[0];
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) vb = jb == j ? out[j] : vb;
+                    dp[jb] = (uint8_t)vb;
+                }
             }
         }
     }
@@ -220,7 +255,19 @@ __global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __res
         __builtin_nontemporal_store(q0, reinterpret_cast<nt_u32x4*>(d));
         __builtin_nontemporal_store(q1, reinterpret_cast<nt_u32x4*>(d + 4));
     } else {
-        for (int i = 0; i < 8 && x0 + i < L.w; ++i) d[i] = (int)o[i];
+        // ragged last group of a row: its w - x0 valid pixels as 4 + 2 + 1 (a third of the wavefronts of a 1241-pixel row
+        // pass through here, so eight predicated single stores were ~10 % of the kernel's instructions)
+        const int nv = L.w - x0;                             // 1..7
+        int o0 = 0;
+        if (nv & 4) { *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]); o0 = 4; }
+        if (nv & 2) { *reinterpret_cast<uint2*>(d + o0) = o0 ? make_uint2(o[4], o[5]) : make_uint2(o[0], o[1]); }
+        if (nv & 1) {
+            const int jb = nv - 1;
+            unsigned vb = o[0];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) vb = jb == j ? o[j] : vb;
+            d[jb] = (int)vb;
+        }
     }
 }
 
