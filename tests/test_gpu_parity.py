@@ -1088,6 +1088,106 @@ def test_native_frame_state_edges_float32_staging_buffer_empty_and_overflow(fe):
     small.close()
 
 
+def test_framestate_c_abi_raw_calls_pitched_frames_bad_arguments_two_objects(fe):
+    """vofe_framestate_* called straight through ctypes, as a C host would: frames handed over with a row pitch larger
+    than the width, argument errors (NULL pointers, pitch below the width, bad parameters) answered with VOFE_E_ARG and a
+    message instead of a fault, and two objects on one GPU advanced in turn (each owns its streams and buffers) giving
+    what one object gives alone."""
+    import ctypes as C
+    from visual_odometry_amd import _lib
+    L = _lib.load()
+    H, W = 200, 300
+    frames = _seq(H, W, 23, 4)
+    pitched = [np.zeros((H, W + 52), np.uint8) for _ in frames]
+    for dst, src in zip(pitched, frames):
+        dst[:, :W] = src
+        dst[:, W:] = 255                                          # must never be read as pixels
+    p = _lib.FrameStateParams()
+    p.height, p.width, p.win_w, p.win_h, p.max_level = H, W, 21, 21, 3
+    p.crit_type, p.max_count, p.eps, p.min_eig_thr, p.fb_thresh = 3, 30, 0.01, 1e-3, 1.0
+    p.max_corners, p.quality_level, p.min_distance = 200, 0.01, 10.0
+    p.thr_new_keypoints, p.thr_triangulation, p.thr_candidates_min, p.thr_candidates_max = 15.0, 3.0, 0.5, 100.0
+    p.thr_alpha_rad = float(np.deg2rad(0.02))
+    p.cap_landmarks, p.cap_candidates, p.first_is_f64 = 1024, 1024, 1
+    p.K[:] = [250.0, 0, 150, 0, 250.0, 100, 0, 0, 1.0]
+    h = C.c_void_p()
+    bad = _lib.FrameStateParams.from_buffer_copy(p)
+    bad.max_corners = 0
+    assert L.vofe_framestate_create(0, C.byref(bad), C.byref(h)) == -1 and not h.value
+    assert L.vofe_framestate_create(0, None, C.byref(h)) == -1
+    assert L.vofe_framestate_create(99, C.byref(p), C.byref(h)) != 0 and not h.value
+    assert b"device" in L.vofe_last_error()
+    objs = []
+    for _ in range(3):
+        assert L.vofe_framestate_create(0, C.byref(p), C.byref(h)) == 0, L.vofe_last_error()
+        objs.append(C.c_void_p(h.value))
+    first = oracle.goodFeaturesToTrack(frames[0], 200, 0.01, 10).reshape(-1, 2)
+    P0 = np.ascontiguousarray(first[:60])
+    X0 = np.ascontiguousarray(np.random.default_rng(2).normal(0, 4, (60, 3)) + [0, 0, 15])
+    C0 = np.ascontiguousarray(first[60:])
+    F0 = C0.astype(np.float64)
+    pose0 = np.eye(4)[:3].reshape(-1)
+    T0 = np.ascontiguousarray(np.tile(pose0, (C0.shape[0], 1)))
+
+    def reset(o, img):
+        return L.vofe_framestate_reset(o, img.ctypes.data, img.strides[0], P0.ctypes.data, X0.ctypes.data, P0.shape[0], C0.ctypes.data,
+                                       F0.ctypes.data, T0.ctypes.data, C0.shape[0])
+
+    xy, st, k, nf, kept = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+
+    def track(o, img):
+        rc = L.vofe_framestate_track(o, img.ctypes.data, img.strides[0], C.byref(xy), C.byref(st), C.byref(k), C.byref(nf), C.byref(kept))
+        assert rc == 0, L.vofe_last_error()
+        n = k.value
+        return (np.ctypeslib.as_array(C.cast(xy, C.POINTER(C.c_float)), shape=(n, 2)).copy(),
+                np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(n,)).copy(), nf.value, kept.value)
+
+    def state(o):
+        a, b = C.c_int(), C.c_int()
+        assert L.vofe_framestate_counts(o, C.byref(a), C.byref(b)) == 0
+        Pq, Cq = np.empty((a.value, 2), np.float32), np.empty((b.value, 2), np.float32)
+        Fq, Tq = np.empty((b.value, 2), np.float64), np.empty((b.value, 12), np.float64)
+        assert L.vofe_framestate_download(o, Pq.ctypes.data, Cq.ctypes.data, Fq.ctypes.data, Tq.ctypes.data) == 0
+        return Pq, Cq, Fq, Tq
+
+    a, b, solo = objs
+    # argument errors: no fault, no state change
+    assert L.vofe_framestate_track(a, pitched[1].ctypes.data, pitched[1].strides[0], C.byref(xy), C.byref(st), C.byref(k), None, None) == -1   # before reset
+    assert L.vofe_framestate_reset(a, None, W, P0.ctypes.data, X0.ctypes.data, 60, None, None, None, 0) == -1
+    assert L.vofe_framestate_reset(a, frames[0].ctypes.data, W - 1, P0.ctypes.data, X0.ctypes.data, 60, None, None, None, 0) == -1
+    assert L.vofe_framestate_reset(a, frames[0].ctypes.data, W, None, None, 60, None, None, None, 0) == -1
+    assert L.vofe_framestate_reset(a, frames[0].ctypes.data, W, P0.ctypes.data, X0.ctypes.data, 5000, None, None, None, 0) == -1
+    assert b"capacit" in L.vofe_last_error()
+    for o, img in ((a, pitched[0]), (b, frames[0]), (solo, frames[0])):
+        assert reset(o, img) == 0, L.vofe_last_error()
+    assert L.vofe_framestate_track(a, pitched[1].ctypes.data, W - 4, C.byref(xy), C.byref(st), C.byref(k), None, None) == -1
+    assert L.vofe_framestate_update(a, pose0.ctypes.data, None, None) == -1                       # before track
+    for t in range(1, 4):
+        pose = np.eye(4)[:3]
+        pose[:, 3] = [0.03 * t, 0, 0.5 * t]
+        pose = np.ascontiguousarray(pose.reshape(-1))
+        # a: pitched frames; b: contiguous frames, its calls interleaved with a's; solo: alone, afterwards
+        ta = track(a, pitched[t])
+        tb = track(b, frames[t])
+        assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1], tb[1]) and ta[2:] == tb[2:]
+        assert L.vofe_framestate_update(b, None, ta[1].ctypes.data, None) == -1                  # NULL pose
+        keep = np.ascontiguousarray((ta[1] == 1).astype(np.uint8))
+        prom_a, prom_b = C.c_int(), C.c_int()
+        assert L.vofe_framestate_update_async(a, pose.ctypes.data, keep.ctypes.data) == 0
+        assert L.vofe_framestate_update(b, pose.ctypes.data, keep.ctypes.data, C.byref(prom_b)) == 0
+        assert L.vofe_framestate_wait(a, C.byref(prom_a)) == 0 and prom_a.value == prom_b.value
+        ts = track(solo, frames[t])
+        assert np.array_equal(ts[0], ta[0]) and np.array_equal(ts[1], ta[1])
+        assert L.vofe_framestate_update(solo, pose.ctypes.data, keep.ctypes.data, None) == 0
+        sa, sb, ss = state(a), state(b), state(solo)
+        for x, y, z in zip(sa, sb, ss):
+            assert np.array_equal(x, y) and np.array_equal(x, z), t
+    assert state(a)[0].shape[0] > 0 and state(a)[1].shape[0] > 50
+    for o in objs:
+        assert L.vofe_framestate_destroy(o) == 0
+    assert L.vofe_framestate_destroy(None) == 0
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

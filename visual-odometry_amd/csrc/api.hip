@@ -54,6 +54,9 @@ static inline long long align_up(long long v, long long a) { return (v + a - 1) 
 // Every launching entry point makes the ctx's device current for the calling thread (a thread-local read when it
 // already is), so a process that drives several GPUs from one thread cannot launch on the wrong one.
 static int bind_device(const vofe_ctx* ctx) {
+    // The launchers check hipGetLastError() after a launch; that call also returns whatever an EARLIER runtime call of this
+    // thread left behind (its caller has had that code already), which would be reported as this entry point's failure.
+    (void)hipGetLastError();
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return VOFE_OK;
     VOFE_HIP(hipSetDevice(ctx->device));

@@ -51,6 +51,7 @@ size_t first_size(const vofe_framestate* fs) { return fs->p.first_is_f64 ? sizeo
 
 void release(vofe_framestate* fs) {
     if (!fs) return;
+    if (!fs->c_trk) { delete fs; return; }       // nothing was created (the device was never validated: do not touch it)
     hipSetDevice(fs->device);
     if (fs->s_trk) hipStreamSynchronize(fs->s_trk);
     if (fs->s_det) hipStreamSynchronize(fs->s_det);
