@@ -492,11 +492,12 @@ def test_gftt_batch(fe):
         assert np.array_equal(out[i, :cnt[i]], ref.reshape(-1, 2))
 
 
-@pytest.mark.parametrize("chain", ["merged", "split"])
+@pytest.mark.parametrize("chain", ["merged", "split", "rank"])
 def test_gftt_launch_chains_agree(fe, knob, chain):
-    """The detector's default chain (NMS with the bucket scan in its last block, one-block last stage) and the longer
-    chain of separate launches (VOFE_GFTT_CHAIN=split) on the reference's settings, on whole lists, without
-    suppression, masked, on tied scores and batched: identical to the oracle either way."""
+    """The detector's last stage in its three forms -- default (one block for short rank prefixes, the order-preserving
+    multi-block compaction for long ones), VOFE_GFTT_CHAIN=split (round 1's gather / rank_count / emit always) and =rank
+    (one block for short prefixes, round 1's chain for long ones) -- on the reference's settings, on whole lists, without
+    suppression, masked, on tied scores, on lists longer than one block holds, and batched: identical to the oracle."""
     import torch
     knob("VOFE_GFTT_CHAIN", chain)
     a = _seq(376, 1241, 0, 1)[0]
@@ -507,6 +508,12 @@ def test_gftt_launch_chains_agree(fe, knob, chain):
         assert np.array_equal(fe.goodFeaturesToTrack(chk, 0, 0.01, md), oracle.goodFeaturesToTrack(chk, 0, 0.01, md))
     mask = np.zeros_like(a); mask[40:300, 100:1100] = 1
     assert np.array_equal(fe.goodFeaturesToTrack(a, 500, 0.01, 8, mask=mask), oracle.goodFeaturesToTrack(a, 500, 0.01, 8, mask=mask))
+    # long lists (more candidates than the one-block stage holds): whole list with and without suppression, an odd pixel
+    # count, and a prefix that has to be widened (few corners asked for first, so the next call's list guess is short)
+    big = _seq(701, 903, 31, 1)[0]
+    for maxc, q, md in ((0, 0.0005, 2), (0, 0.0005, 0), (20000, 0.0005, 3), (40000, 0.0002, 1.5), (6000, 0.0005, 6)):
+        ref = oracle.goodFeaturesToTrack(big, maxc, q, md, nthreads=8)
+        assert np.array_equal(fe.goodFeaturesToTrack(big, maxc, q, md), ref), (maxc, q, md, ref.shape)
     imgs = np.stack([_seq(200, 300, 40 + i, 1)[0] for i in range(4)])
     out, cnt = fe.goodFeaturesToTrack_batch(torch.from_numpy(imgs).cuda(), 300, 0.01, 9)
     out = out.cpu().numpy()

@@ -40,7 +40,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->nms_rows = env_int("VOFE_NMS_ROWS", 0);
     k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
-    if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : 0;
+    if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : (v[0] == 'r' ? 'r' : 0);
     k->sel_blocks = env_int("VOFE_SEL_BLOCKS", 1024);
     k->sel_launches = env_int("VOFE_SEL_LAUNCHES", 1);
     k->sel_passes = env_int("VOFE_SEL_PASSES", 2);

@@ -40,7 +40,7 @@ struct GfttHdr {
                                    // same-address atomics serialise (~10 ns each), the readers take the max of all
     unsigned n_cand;
     unsigned n_acc;
-    unsigned pad;
+    unsigned scat_lim;          // buckets below this one hold the first rank prefix: the first scatter launch takes only those
     unsigned undecided[SELECT_ROUNDS];
     unsigned seg_end[N_SEG];    // prefix lengths of the bucket-ordered candidate list (bucket boundaries)
     unsigned fin_state;         // finish_small: 1 = corners emitted, 2 = prefix too long for one block (host runs the split chain)
@@ -405,12 +405,15 @@ __device__ __forceinline__ void bucket_scan_body(unsigned* __restrict__ hist_img
         // a prefix that is already a sizeable part of the list is not worth a possible second pass
         if (k == N_SEG - 1 || want > n || (unsigned long long)n <= (unsigned long long)full_ratio * base) want = n;
         const unsigned tk = (unsigned)want;
-        if (tk == 0) { if (t == 0) hd->seg_end[k] = 0; continue; }
+        if (tk == 0) { if (t == 0) { hd->seg_end[k] = 0; if (k == 0) hd->scat_lim = 0; } continue; }
         if (!(first < tk && e0 >= tk)) continue;              // the boundary bucket is not among this thread's
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const unsigned end_i = (i + 1 < BPT) ? cnt[i + 1] : e0;
-            if (cnt[i] < tk && end_i >= tk) hd->seg_end[k] = end_i;
+            if (cnt[i] < tk && end_i >= tk) {
+                hd->seg_end[k] = end_i;
+                if (k == 0) hd->scat_lim = (unsigned)(t * BPT + i + 1);
+            }
         }
     }
 }
@@ -469,7 +472,12 @@ __global__ __launch_bounds__(256) void nms_map(const float* __restrict__ score, 
 // list -> state map -> key map.
 __global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict__ state, const unsigned* __restrict__ ckey, int h, int w,
                                                       unsigned* __restrict__ cursor, unsigned* __restrict__ sorted,
-                                                      unsigned* __restrict__ lkey, uint8_t* __restrict__ lflag) {
+                                                      unsigned* __restrict__ lkey, uint8_t* __restrict__ lflag,
+                                                      const GfttHdr* __restrict__ hdr, int rest) {
+    // rest == 0: only the buckets of the first rank prefix (what the selection reads; on a 4K frame that is a tenth of the
+    // candidates, and every scattered candidate is a returning memory-side atomic); rest == 1: the others, launched only
+    // when a pass has to widen the prefix.  The cursors of the two sets of buckets are disjoint.
+    const unsigned lim = hdr[blockIdx.y].scat_lim;
     const size_t px = (size_t)h * w;
     const uint16_t* stt = state + (size_t)blockIdx.y * px;
     unsigned* cs = cursor + (size_t)blockIdx.y * N_COPY * N_BUCKET;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256) void bucket_scatter(const uint16_t* __restrict
         if (!(v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | v[7])) continue;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (!v[i]) continue;
+            if (!v[i] || ((v[i] >> 2) < lim) == (rest != 0)) continue;
             const unsigned p = (unsigned)(e0 + i);
             const int y = (int)(p / (unsigned)w), x = (int)(p - (unsigned)y * w);
             const unsigned pos = atomicAdd(&cs[(size_t)tile_copy(x, y) * N_BUCKET + (v[i] >> 2)], 1u);
@@ -924,6 +932,125 @@ __global__ __launch_bounds__(1024) void finish_small(int h, int w, GfttHdr* __re
     if (host_hdr && t < sizeof(GfttHdr) / 4) reinterpret_cast<unsigned*>(host_hdr + img)[t] = reinterpret_cast<const unsigned*>(hd)[t];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Last stage for LONG rank prefixes (more candidates than finish_small's one block holds: whole lists, 4K frames): the
+// same idea over many blocks.  The candidate list is in bucket order, so an order-preserving compaction of the accepted
+// candidates is sorted except inside runs of equal bucket, and rank = run start + number of larger keys in the run.
+//   fin_count:     accepted candidates per tile of FT list entries                          -> tile counts
+//   fin_compact:   tile base = sum of the counts before it; keys (score bits << 32 | pixel) -> keys[], in list order
+//   fin_rank_emit: run bounds by walking the neighbours' buckets, rank inside the run, (x, y) to rank order, header out
+// O(n) instead of the O(n^2 / tile) key comparisons of rank_count (4K frame: 46 us -> one launch of a few us).
+constexpr unsigned FT = 4096;                    // list entries per tile (4 per thread of a 1024-thread block)
+__global__ __launch_bounds__(1024) void fin_count(const GfttHdr* __restrict__ hdr, size_t px, const uint8_t* __restrict__ lflag,
+                                                  int take_all, int seg, unsigned* __restrict__ tile_cnt) {
+    __shared__ unsigned s_w[16];
+    const size_t ib = (size_t)blockIdx.y * px;
+    const unsigned n = hdr[blockIdx.y].seg_end[seg];
+    const unsigned ntile = (n + FT - 1) / FT;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const unsigned c0 = tile * FT + 4u * t;
+        unsigned cnt = 0;
+        for (unsigned i = 0; i < 4; ++i) if (c0 + i < n) cnt += take_all ? 1u : (unsigned)(lflag[ib + c0 + i] & 1);
+        for (int o = 32; o > 0; o >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, o);
+        if (lane == 0) s_w[wv] = cnt;
+        __syncthreads();
+        if (t == 0) {
+            unsigned tot = 0;
+            for (int q = 0; q < 16; ++q) tot += s_w[q];
+            tile_cnt[ib + tile] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void fin_compact(GfttHdr* __restrict__ hdr, size_t px, const unsigned* __restrict__ cand,
+                                                    const unsigned* __restrict__ lkey, const uint8_t* __restrict__ lflag, int take_all,
+                                                    int seg, const unsigned* __restrict__ tile_cnt, unsigned long long* __restrict__ keys,
+                                                    uint4* __restrict__ zero_me) {
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_base;
+    const size_t ib = (size_t)blockIdx.y * px;
+    const unsigned n = hdr[blockIdx.y].seg_end[seg];
+    const unsigned ntile = (n + FT - 1) / FT;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    (void)zero_me;
+    if (ntile == 0 && blockIdx.x == 0 && t == 0) hdr[blockIdx.y].n_acc = 0u;
+    for (unsigned tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        // base of this tile: the counts of all tiles before it
+        unsigned part = 0;
+        for (unsigned j = t; j < tile; j += 1024) part += tile_cnt[ib + j];
+        for (int o = 32; o > 0; o >>= 1) part += (unsigned)__shfl_xor((int)part, o);
+        if (lane == 0) s_w[wv] = part;
+        __syncthreads();
+        if (t == 0) {
+            unsigned tot = 0;
+            for (int q = 0; q < 16; ++q) tot += s_w[q];
+            s_base = tot;
+        }
+        __syncthreads();
+        const unsigned base = s_base;
+        __syncthreads();
+        // this thread's four entries, in list order
+        const unsigned c0 = tile * FT + 4u * t;
+        unsigned fl[4], cnt = 0;
+#pragma unroll
+        for (unsigned i = 0; i < 4; ++i) {
+            fl[i] = (c0 + i < n) ? (take_all ? 1u : (unsigned)(lflag[ib + c0 + i] & 1)) : 0u;
+            cnt += fl[i];
+        }
+        unsigned inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = (unsigned)__shfl_up((int)inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        unsigned off = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) { off += q < wv ? s_w[q] : 0u; tot += s_w[q]; }
+        unsigned pos = base + off + inc - cnt;
+#pragma unroll
+        for (unsigned i = 0; i < 4; ++i)
+            if (fl[i]) keys[ib + pos++] = ((unsigned long long)lkey[ib + c0 + i] << 32) | cand[ib + c0 + i];
+        if (tile == ntile - 1 && t == 0) hdr[blockIdx.y].n_acc = base + tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void fin_rank_emit(const GfttHdr* __restrict__ hdr, size_t px, const unsigned long long* __restrict__ keys,
+                                                     int w, float* __restrict__ corners, int out_stride, int max_out,
+                                                     GfttHdr* __restrict__ host_hdr, float* __restrict__ host_corners) {
+    if (host_hdr && blockIdx.x == 0 && threadIdx.x < sizeof(GfttHdr) / 4)
+        reinterpret_cast<unsigned*>(host_hdr + blockIdx.y)[threadIdx.x] = reinterpret_cast<const unsigned*>(hdr + blockIdx.y)[threadIdx.x];
+    const GfttHdr* hd = hdr + blockIdx.y;
+    const unsigned na = hd->n_acc;
+    if (na > RANK_MAX) return;                                   // the host runs the bitonic network over keys[] instead
+    BucketMap bm;
+    bm.mb = hd->bm_mb; bm.shift = hd->bm_shift;
+    const unsigned long long* g = keys + (size_t)blockIdx.y * px;
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < na; j += gridDim.x * 256) {
+        const unsigned long long key = g[j];
+        const unsigned d = bucket_of(bm, (unsigned)(key >> 32));
+        unsigned rk = j;                                         // = run start + larger keys in the run, counted outwards from j
+        for (unsigned k = j; k > 0; --k) {                       // earlier members of the run: those with a smaller key move behind
+            const unsigned long long o = g[k - 1];
+            if (bucket_of(bm, (unsigned)(o >> 32)) != d) break;
+            if (o < key) --rk;
+        }
+        for (unsigned k = j + 1; k < na; ++k) {                  // later members of the run: those with a larger key move in front
+            const unsigned long long o = g[k];
+            if (bucket_of(bm, (unsigned)(o >> 32)) != d) break;
+            if (o > key) ++rk;
+        }
+        if (rk >= (unsigned)max_out) continue;
+        const unsigned p = (unsigned)(key & 0xffffffffull);
+        const unsigned y = p / (unsigned)w;
+        const float2 c = make_float2((float)(p - y * w), (float)y);
+        reinterpret_cast<float2*>(corners)[(size_t)blockIdx.y * out_stride + rk] = c;
+        if (host_corners) reinterpret_cast<float2*>(host_corners)[rk] = c;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1141,7 +1268,8 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     hipLaunchKernelGGL(bucket_scan, dim3(batch), dim3(1024), 0, st, hist, cursor, hdr, seg_base, (unsigned)sel_full, quality); }
     { VOFE_TIMED(ctx, "bucket_scatter");
     hipLaunchKernelGGL(bucket_scatter, dim3((unsigned)std::min<size_t>((px + 2047) / 2048, 2048), batch), dim3(256), 0, st,
-                       state, ckey, h, w, cursor, cand, lkey, lflag); }
+                       state, ckey, h, w, cursor, cand, lkey, lflag, hdr, 0); }
+    bool scattered_rest = false;
     int r = 0;
     float md2 = 0.f;
     if (suppress) {
@@ -1158,6 +1286,13 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     const bool use_rank = !kn.gftt_bitonic;                       // VOFE_GFTT_SORT=bitonic forces the network (tests)
     int seg = 0;
     for (int pass = 0;; ++pass) {
+        if (seg > 0 && !scattered_rest) {
+            // the prefix is being widened beyond the buckets the first scatter took: the other candidates join the list now
+            VOFE_TIMED(ctx, "bucket_scatter");
+            hipLaunchKernelGGL(bucket_scatter, dim3((unsigned)std::min<size_t>((px + 2047) / 2048, 2048), batch), dim3(256), 0, st,
+                               state, ckey, h, w, cursor, cand, lkey, lflag, hdr, 1);
+            scattered_rest = true;
+        }
         if (pass > 0) {
             // clear the round flags and the accepted count, keep the rest
             for (int b = 0; b < batch; ++b) {
@@ -1196,7 +1331,24 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
             VOFE_HIP(hipStreamSynchronize(st));
             for (int b = 0; b < batch; ++b) split = split || hh[b].fin_state == 2u;
         }
-        if (split) {
+        // long prefixes: order-preserving multi-block compaction + in-run ranks (VOFE_GFTT_CHAIN=split / rank keep round 1's
+        // gather / rank_count / emit chain for the tests)
+        const bool ordered = split && use_rank && max_out > 0 && kn.gftt_chain == 0;
+        if (ordered) {
+            unsigned long long ub = whole ? (last ? std::max<unsigned long long>(last, 1) : px) : ((unsigned long long)seg_base << seg);
+            ub = std::min<unsigned long long>(ub + ub / 4 + FT, px);
+            const unsigned gt = (unsigned)std::min<unsigned long long>((ub + FT - 1) / FT, 512);
+            { VOFE_TIMED(ctx, "fin_count");
+            hipLaunchKernelGGL(fin_count, dim3(gt, batch), dim3(1024), 0, st, hdr, px, lflag, suppress ? 0 : 1, seg, rank); }
+            { VOFE_TIMED(ctx, "fin_compact");
+            hipLaunchKernelGGL(fin_compact, dim3(gt, batch), dim3(1024), 0, st, hdr, px, cand, lkey, lflag, suppress ? 0 : 1, seg, rank, keys,
+                               (uint4*)nullptr); }
+            const unsigned ge = (unsigned)std::min<unsigned long long>((std::min<unsigned long long>(ub, RANK_MAX) + 255) / 256, 1024);
+            { VOFE_TIMED(ctx, "fin_rank_emit");
+            hipLaunchKernelGGL(fin_rank_emit, dim3(std::max(ge, 1u), batch), dim3(256), 0, st, hdr, px, keys, w, d_corners_xy, capacity, max_out,
+                               reinterpret_cast<GfttHdr*>(ctx->d_pinned), stage_floats ? reinterpret_cast<float*>(ctx->d_pinned + hdr_ints) : nullptr); }
+            VOFE_HIP(hipStreamSynchronize(st));
+        } else if (split) {
         { VOFE_TIMED(ctx, "gather_accepted");
         hipLaunchKernelGGL(gather_accepted, dim3(256, batch), dim3(256), 0, st, ckey, h, w, hdr, state, cand, keys,
                            rank, suppress ? 0 : 1, seg); }

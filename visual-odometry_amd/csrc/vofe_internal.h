@@ -33,7 +33,7 @@ struct VofeKnobs {
     int nms_rows;             // VOFE_NMS_ROWS: rows per thread of the NMS kernel, 1 / 2 / 4 / 8 (0 = by launch size)
     bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
     bool gftt_debug;          // VOFE_GFTT_DEBUG
-    char gftt_chain;          // VOFE_GFTT_CHAIN: 's'plit = the detector's last stage as three launches (round 1's chain)
+    char gftt_chain;          // VOFE_GFTT_CHAIN: 's'plit = the last stage always as gather / rank_count / emit (round 1's chain); 'r'ank = that chain for long prefixes only
     int sel_blocks, sel_launches, sel_passes, sel_spins, sel_prefix, sel_full;   // VOFE_SEL_*
 };
 
