@@ -42,6 +42,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
     if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : (v[0] == 'r' ? 'r' : 0);
     k->sel_blocks = env_int("VOFE_SEL_BLOCKS", 1024);
+    k->sel_blocks_set = getenv("VOFE_SEL_BLOCKS") != nullptr;
     k->sel_launches = env_int("VOFE_SEL_LAUNCHES", 1);
     k->sel_passes = env_int("VOFE_SEL_PASSES", 2);
     k->sel_spins = env_int("VOFE_SEL_SPINS", 64);

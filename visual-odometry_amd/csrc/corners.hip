@@ -1213,7 +1213,9 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
     // schedule of the selection (measured, profiles/r01_host_paths.txt; any values give the same corners, see
     // tools/knob_matrix.sh): one launch of 4096 waves, two sweeps, a blocked candidate polls its blockers up to 64 times
     const VofeKnobs& kn = ctx->knobs;
-    const int sel_blocks = std::max(kn.sel_blocks, 1);
+    // (a batch shares the chip: with 1024 blocks per image most of a short prefix's waves find no candidate and the launch is
+    // bound by wave start-up; 64 images: 196 -> 150 us with 64 blocks per image, tools/gftt_batch_bench.py)
+    const int sel_blocks = std::max(kn.sel_blocks_set ? kn.sel_blocks : std::max(64, kn.sel_blocks / std::max(batch, 1)), 1);
     const int sel_launches = std::min(std::max(kn.sel_launches, 1), SELECT_ROUNDS);
     const int sel_passes = std::max(kn.sel_passes, 1);
     const int sel_spins = std::max(kn.sel_spins, 0);

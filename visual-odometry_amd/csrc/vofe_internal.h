@@ -35,6 +35,7 @@ struct VofeKnobs {
     bool gftt_debug;          // VOFE_GFTT_DEBUG
     char gftt_chain;          // VOFE_GFTT_CHAIN: 's'plit = the last stage always as gather / rank_count / emit (round 1's chain); 'r'ank = that chain for long prefixes only
     int sel_blocks, sel_launches, sel_passes, sel_spins, sel_prefix, sel_full;   // VOFE_SEL_*
+    bool sel_blocks_set;      // VOFE_SEL_BLOCKS was given (otherwise the block count per image shrinks with the batch)
 };
 
 // Measurement aid (vofe_profile_begin / vofe_profile_end): while a context profiles, every kernel launch of the
