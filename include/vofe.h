@@ -201,6 +201,19 @@ int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_
                           void* d_first_out, double* d_transform_out, uint8_t* d_triangulate_out,
                           int* d_count_out, int* h_count_out);
 
+/* Replaces the point bookkeeping of the bootstrap loop, reference initialization.py:54-64 (and :69-70):
+ *     good_old = good_old[status.flatten() == 1];  good_new = tracked_points[status.flatten() == 1]
+ *     distances = np.sqrt(np.sum((good_new - good_old) ** 2, axis=2)).flatten()
+ *     drop = np.where(distances < dist_threshold_move);  good_old / good_new = np.delete(.., drop, axis=0)
+ * d_new_xy (n,2) f32 are the points vofe_lk_track returned, d_flag (n) its status, d_old_xy (n,2) f32 the positions of the
+ * same points in the first bootstrap image.  A pair is kept iff flag == 1 and NOT (distance < dist_move), the distance
+ * evaluated in float32 with numpy's decisions (a NaN distance is not below the threshold: the pair stays, as np.delete
+ * leaves it).  With d_flag = the inlier mask of cv2.findEssentialMat and dist_move = 0 the same call is
+ * good_old[mask.flatten() == 1] / good_new[mask.flatten() == 1] (:69-70).  Kept pairs are written densely, in input order,
+ * to d_new_out / d_old_out, each of which may be the buffer its input came from; count as in vofe_candidate_filter. */
+int vofe_pair_filter(vofe_ctx* ctx, const float* d_new_xy, const uint8_t* d_flag, const float* d_old_xy, int n,
+                     double dist_move, float* d_new_out, float* d_old_out, int* d_count_out, int* h_count_out);
+
 /* Replaces the per-candidate triangulation loop of reference continuous.py:450-485 (cv2.triangulatePoints per
  * candidate, negative-depth test, baseline angle of continuous.py:274-309) with one launch over all candidates.
  * d_K is the 3x3 intrinsic matrix and d_pose the current 3x4 pose (row-major float64, device); d_cur_xy (n,2) f32,

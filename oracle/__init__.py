@@ -334,3 +334,27 @@ def handle_candidates(K, img_current, img_prev, Ci, Fi, Ti, Pi, Xi, pose, max_co
         Fi = np.hstack([Fi, new_features])
         Ti = np.hstack([Ti, tiled_pose])
     return Pi, Xi, Ci, Fi, Ti
+
+
+def bootstrap_correspondences(imgs, params, essential_mask):
+    """The front-end part of Initialization.get_features_and_k, reference initialization.py:41-70, on this oracle's
+    goodFeaturesToTrack / calcOpticalFlowPyrLK; `essential_mask(good_new, good_old)` stands in for the inlier mask of
+    cv2.findEssentialMat (:67-68, CPU geometry, out of scope).  Returns (good_old, good_new) and the pairs after every step."""
+    corners = goodFeaturesToTrack(imgs[0], params["maxCorners"], params["qualityLevel"], params["minDistance"])
+    good_old = np.float32(corners).reshape(-1, 1, 2)
+    good_new = good_old
+    steps = []
+    for i in range(len(imgs) - 1):
+        tracked_points, status, _ = calcOpticalFlowPyrLK(imgs[i], imgs[i + 1], good_new, None, winSize=params["winSize"],
+                                                         maxLevel=0, criteria=(3, 30, 0.01))
+        good_old = good_old[status.flatten() == 1]
+        good_new = tracked_points[status.flatten() == 1]
+        distances = np.sqrt(np.sum((good_new - good_old) ** 2, axis=2)).flatten()
+        drop = np.where(distances < params["dist_threshold_move"])
+        good_old = np.delete(good_old, drop, axis=0)
+        good_new = np.delete(good_new, drop, axis=0)
+        steps.append((good_old.copy(), good_new.copy()))
+        mask = np.asarray(essential_mask(good_new, good_old))
+        good_old = good_old[mask.flatten() == 1]
+        good_new = good_new[mask.flatten() == 1]
+    return good_old, good_new, steps

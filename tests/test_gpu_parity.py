@@ -1195,6 +1195,119 @@ def test_framestate_c_abi_raw_calls_pitched_frames_bad_arguments_two_objects(fe)
     assert L.vofe_framestate_destroy(None) == 0
 
 
+# ------------------------------------------------------------------ bootstrap front end (initialization.py:41-70)
+def _pseudo_ransac_mask(good_new, good_old):
+    """Deterministic stand-in for the inlier mask of cv2.findEssentialMat (CPU geometry, out of scope): depends on the
+    pair values only, so both sides see the same mask as long as their pairs agree."""
+    key = np.floor(good_new[:, 0, 0] * 4) + 3 * np.floor(good_old[:, 0, 1])
+    return (key.astype(np.int64) % 9 != 0).astype(np.uint8).reshape(-1, 1)
+
+
+@pytest.mark.parametrize("dataset,h,w,stride,move", [("kitti", 376, 1241, 2, None), ("parking", 480, 640, 1, None),
+                                                     ("malaga", 600, 800, 2, None), ("kitti", 376, 1241, 2, 4.37),
+                                                     ("parking", 200, 320, 1, 1.56)])
+def test_bootstrap_tracker_follows_the_reference_loop(fe, dataset, h, w, stride, move):
+    """Initialization.get_features_and_k up to the essential matrix, with the reference's own bootstrap settings per
+    dataset (single-level forward LK, 11x11 / 41x41 windows, minEigThreshold 1e-4, 3 / 7 / 5 images): the device-resident
+    twin returns the oracle's pairs after every image, bit for bit; plus thresholds that split the set."""
+    from visual_odometry_amd import BOOTSTRAP_PRESETS
+    from visual_odometry_amd.bootstrap import BootstrapTracker, bootstrap_correspondences
+    params = dict(BOOTSTRAP_PRESETS[dataset])
+    if move is not None:
+        params["dist_threshold_move"] = move
+    n_img = params["n_images"]
+    frames = _seq(h, w, 31 + h, (n_img - 1) * stride + 1)[::stride]
+    ro, rn, steps = oracle.bootstrap_correspondences(frames, params, _pseudo_ransac_mask)
+    bt = BootstrapTracker(h, w, frontend=fe, **params)
+    n0 = bt.detect(frames[0])
+    assert n0 == oracle.goodFeaturesToTrack(frames[0], params["maxCorners"], 0.01, 10).shape[0]
+    for i, img in enumerate(frames[1:]):
+        go, gn = bt.track(img)
+        assert go.dtype == np.float32 and go.shape == steps[i][0].shape and go.shape[1:] == (1, 2), (i, go.shape, steps[i][0].shape)
+        assert np.array_equal(go, steps[i][0]) and np.array_equal(gn, steps[i][1]), "image %d" % (i + 1)
+        bt.keep(_pseudo_ransac_mask(gn, go))
+    go, gn = bt.pairs()
+    assert np.array_equal(go, ro) and np.array_equal(gn, rn)
+    assert 10 < len(ro) < n0                                 # the rules removed some pairs and left some
+    if move is not None:
+        d = np.sqrt(np.sum((steps[0][1] - steps[0][0]) ** 2, axis=2)).flatten()
+        assert d.min() >= np.float32(move) and len(steps[0][0]) < n0
+    # the one-call form
+    fo, fn = bootstrap_correspondences(frames, params, _pseudo_ransac_mask, frontend=fe)
+    assert np.array_equal(fo, ro) and np.array_equal(fn, rn)
+
+
+def test_pair_filter_c_abi_numpy_decisions_nan_in_place(fe):
+    """vofe_pair_filter raw: float32 distance decisions of numpy at thresholds that sit on / next to representable
+    distances, NaN and infinite coordinates (a NaN distance is not below the threshold: kept), in place and out of place,
+    the mask form (threshold 0), n = 0 and argument errors."""
+    import ctypes as C
+    import torch
+    L, ctx = fe.L, fe.ctx
+    rng = np.random.default_rng(77)
+    for n, thr in ((0, 2.0), (1, 0.0), (63, 5.0), (1024, 2.0), (1025, 3.0000002), (5000, 2.9999998), (3000, -1.0), (3000, float("inf")),
+                   (2000, float("nan"))):
+        old = np.round(rng.uniform(0, 600, (n, 2))).astype(np.float32)
+        step = rng.integers(-4, 5, (n, 2)).astype(np.float32)                 # many distances are exactly 3, 5, sqrt(8) ...
+        new = (old + step + (rng.random((n, 2)) < 0.2) * rng.normal(0, 1e-6, (n, 2))).astype(np.float32)
+        if n > 10:
+            new[3] = np.nan; new[5, 0] = np.inf; old[7, 1] = np.nan; new[9] = old[9]
+        flag = rng.integers(0, 3, n).astype(np.uint8)                         # 0, 1, 2: only == 1 passes
+        keep = flag == 1
+        with np.errstate(invalid="ignore"):
+            dist = np.sqrt(np.sum((new[keep].reshape(-1, 1, 2) - old[keep].reshape(-1, 1, 2)) ** 2, axis=2)).flatten()
+            drop = np.where(dist < thr)
+        r_old, r_new = np.delete(old[keep], drop, axis=0), np.delete(new[keep], drop, axis=0)
+        for in_place in (False, True):
+            d_new, d_old, d_flag = torch.from_numpy(new).cuda(), torch.from_numpy(old).cuda(), torch.from_numpy(flag).cuda()
+            o_new = d_new if in_place else torch.full((max(n, 1), 2), -7.0, dtype=torch.float32, device="cuda")
+            o_old = d_old if in_place else torch.full((max(n, 1), 2), -7.0, dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            m = C.c_int(-1)
+            rc = L.vofe_pair_filter(ctx, d_new.data_ptr(), d_flag.data_ptr(), d_old.data_ptr(), n, C.c_double(thr),
+                                    o_new.data_ptr(), o_old.data_ptr(), cnt.data_ptr(), C.byref(m))
+            assert rc == 0 and m.value == len(r_old) == int(cnt.item()), (n, thr, m.value, len(r_old))
+            assert np.array_equal(o_new[:m.value].cpu().numpy(), r_new, equal_nan=True), (n, thr, in_place)
+            assert np.array_equal(o_old[:m.value].cpu().numpy(), r_old, equal_nan=True), (n, thr, in_place)
+            if not in_place and n:
+                assert (o_new[m.value:] == -7.0).all() and (o_old[m.value:] == -7.0).all()     # nothing past the count
+    # asynchronous form (no host count), then errors
+    d = torch.zeros((4, 2), dtype=torch.float32, device="cuda")
+    f = torch.ones(4, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert L.vofe_pair_filter(ctx, d.data_ptr(), f.data_ptr(), d.data_ptr(), 4, C.c_double(0.0), d.data_ptr(), d.data_ptr(), cnt.data_ptr(), None) == 0
+    fe.synchronize()
+    assert int(cnt.item()) == 4
+    m = C.c_int(5)
+    assert L.vofe_pair_filter(None, d.data_ptr(), f.data_ptr(), d.data_ptr(), 4, C.c_double(0.0), d.data_ptr(), d.data_ptr(), cnt.data_ptr(), C.byref(m)) == -1 and m.value == 0
+    assert L.vofe_pair_filter(ctx, d.data_ptr(), f.data_ptr(), d.data_ptr(), -1, C.c_double(0.0), d.data_ptr(), d.data_ptr(), cnt.data_ptr(), None) == -1
+    assert L.vofe_pair_filter(ctx, d.data_ptr(), f.data_ptr(), d.data_ptr(), 4, C.c_double(0.0), d.data_ptr(), d.data_ptr(), None, None) == -1
+    assert L.vofe_pair_filter(ctx, None, f.data_ptr(), d.data_ptr(), 4, C.c_double(0.0), d.data_ptr(), d.data_ptr(), cnt.data_ptr(), None) == -1
+    assert b"vofe_pair_filter" in L.vofe_last_error()
+
+
+def test_bootstrap_tracker_argument_and_order_errors(fe):
+    from visual_odometry_amd import error
+    from visual_odometry_amd.bootstrap import BootstrapTracker
+    a, b = _seq(97, 131, 5, 2)
+    bt = BootstrapTracker(97, 131, frontend=fe, maxCorners=50)
+    with pytest.raises(error):
+        bt.track(b)                                          # before detect
+    with pytest.raises(error):
+        bt.detect(np.zeros((97, 131), np.uint8))             # no corner: the reference fails there as well
+    assert bt.detect(a) > 0
+    with pytest.raises(error):
+        bt.track(b[:50])                                     # wrong size
+    go, gn = bt.track(b)
+    with pytest.raises(error):
+        bt.keep(np.ones(len(go) + 1, np.uint8))
+    assert bt.keep(np.zeros((len(go), 1), np.uint8)) == 0    # RANSAC kept nothing
+    with pytest.raises(error):
+        bt.track(a)                                          # cv2 raises on an empty prevPts
+    with pytest.raises(error):
+        BootstrapTracker(97, 131, frontend=fe, maxCorners=0)
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -429,3 +429,37 @@ def test_triangulation_restatement_recovers_known_points():
     assert pts.shape == (3, int(keep.sum())) and keep.sum() > 10 and not keep[::11].any() and not (keep & ~flags).any()
     none, empty = oracle.triangulate_candidates(K, pose, Ci, Fi, Ti, np.zeros(60, bool))
     assert not none.any() and empty.shape == (3, 0)
+
+
+def test_bootstrap_loop_restatement_follows_known_motion_and_its_rules():
+    """oracle.bootstrap_correspondences (initialization.py:41-70): on the synthetic sequence every surviving pair links a
+    corner of image 0 to where the known warp puts it in the last image; the moved-far-enough rule and the mask are applied
+    after every image (no cv2 here: the loop is pinned by the ground truth and by its own numpy rules, parity unpinned)."""
+    h, w, n_img = 200, 320, 5
+    frames = synthetic.sequence(h, w, seed=9, n_frames=n_img)
+    params = dict(maxCorners=300, qualityLevel=0.01, minDistance=10, winSize=(11, 11), dist_threshold_move=1.5)
+    calls = []
+
+    def mask(good_new, good_old):
+        calls.append(len(good_new))
+        assert good_new.shape == good_old.shape and good_new.dtype == np.float32 and good_new.shape[1:] == (1, 2)
+        d = np.sqrt(np.sum((good_new - good_old) ** 2, axis=2)).flatten()
+        assert (d >= np.float32(1.5)).all()                   # the rule ran before the mask
+        m = np.ones((len(good_new), 1), np.uint8)
+        m[::5] = 0
+        return m
+    good_old, good_new, steps = oracle.bootstrap_correspondences(frames, params, mask)
+    corners = oracle.goodFeaturesToTrack(frames[0], 300, 0.01, 10).reshape(-1, 2)
+    assert len(calls) == n_img - 1 and len(steps) == n_img - 1 and calls == [len(s[0]) for s in steps]
+    assert all(calls[i + 1] <= calls[i] - (calls[i] + 4) // 5 for i in range(len(calls) - 1))
+    assert 20 < len(good_old) == len(good_new) < len(corners)
+    # good_old are corners of image 0, in their original order
+    idx = [int(np.flatnonzero((corners == p).all(axis=1))[0]) for p in good_old.reshape(-1, 2)]
+    assert idx == sorted(idx)
+    t = n_img - 1
+    cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+    z = 1.0 + 0.002 * t
+    px = (good_old[:, 0, 0] - cx - 1.5 * t) * z + cx
+    py = (good_old[:, 0, 1] - cy - 0.4 * t) * z + cy
+    e = np.hypot(good_new[:, 0, 0] - px, good_new[:, 0, 1] - py)
+    assert np.mean(e < 0.25) > 0.9, (np.mean(e < 0.25), np.median(e))

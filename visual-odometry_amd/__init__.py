@@ -21,6 +21,9 @@ def __getattr__(name):
     if name in ("SequenceTracker", "MultiSequenceTracker"):
         from . import sequence
         return getattr(sequence, name)
+    if name in ("BootstrapTracker", "bootstrap_correspondences"):
+        from . import bootstrap
+        return getattr(bootstrap, name)
     if name == "DeviceFrameState":
         from . import device_state
         return device_state.DeviceFrameState

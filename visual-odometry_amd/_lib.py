@@ -12,7 +12,7 @@ SYMBOLS = (
     "vofe_pyramid_create", "vofe_pyramid_free", "vofe_pyramid_build", "vofe_pyramid_levels",
     "vofe_pyramid_level_size", "vofe_pyramid_download", "vofe_pyramid_download_padded",
     "vofe_lk_track", "vofe_track_fb", "vofe_lk_set_counters", "vofe_profile_begin", "vofe_profile_end", "vofe_corner_score", "vofe_gftt", "vofe_gftt_host", "vofe_gftt_batch", "vofe_gftt_noalloc", "vofe_new_feature_mask", "vofe_new_feature_mask2",
-    "vofe_candidate_filter", "vofe_triangulate_candidates", "vofe_candidate_commit",
+    "vofe_candidate_filter", "vofe_pair_filter", "vofe_triangulate_candidates", "vofe_candidate_commit",
     "vofe_framestate_create", "vofe_framestate_destroy", "vofe_framestate_reset", "vofe_framestate_frame_buffer",
     "vofe_framestate_track", "vofe_framestate_update", "vofe_framestate_update_async", "vofe_framestate_wait", "vofe_framestate_counts", "vofe_framestate_landmarks_world",
     "vofe_framestate_download",
@@ -76,6 +76,7 @@ def load():
     L.vofe_new_feature_mask.argtypes = [vp, vp, i, vp, i, d, vp]
     L.vofe_new_feature_mask2.argtypes = [vp, vp, i, vp, i, vp, i, d, vp]
     L.vofe_candidate_filter.argtypes = [vp, vp, vp, vp, i, vp, i, i, d, d, d, vp, vp, vp, vp, vp, ip]
+    L.vofe_pair_filter.argtypes = [vp, vp, vp, vp, i, d, vp, vp, vp, ip]
     L.vofe_triangulate_candidates.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, i, d, vp, vp]
     L.vofe_candidate_commit.argtypes = [vp, vp, vp, i, vp, i, i, i, vp, vp, vp, vp, i, vp, vp, i, i, vp, vp, vp, vp]
     L.vofe_gftt_batch.argtypes = [vp, vp, i, i, i, i, sz, i, d, d, i, i, i, d, vp, i, ip]

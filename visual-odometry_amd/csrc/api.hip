@@ -501,6 +501,24 @@ int vofe_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_
     return VOFE_OK;
 }
 
+int vofe_pair_filter(vofe_ctx* ctx, const float* d_new_xy, const uint8_t* d_flag, const float* d_old_xy, int n,
+                     double dist_move, float* d_new_out, float* d_old_out, int* d_count_out, int* h_count_out) {
+    if (h_count_out) *h_count_out = 0;
+    if (!ctx) { vofe_set_error("vofe_pair_filter: ctx is NULL"); return VOFE_E_ARG; }
+    if (n < 0) { vofe_set_error("vofe_pair_filter: negative count"); return VOFE_E_ARG; }
+    if (!d_count_out) { vofe_set_error("vofe_pair_filter: d_count_out is NULL"); return VOFE_E_ARG; }
+    if (n > 0 && (!d_new_xy || !d_flag || !d_old_xy || !d_new_out || !d_old_out)) {
+        vofe_set_error("vofe_pair_filter: NULL buffer");
+        return VOFE_E_ARG;
+    }
+    VOFE_BIND(ctx);
+    int rc = vofe_launch_pair_filter(ctx, d_new_xy, d_flag, d_old_xy, n, dist_move, d_new_out, d_old_out, d_count_out);
+    if (rc || !h_count_out) return rc;
+    VOFE_HIP(hipMemcpyAsync(h_count_out, d_count_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VOFE_HIP(hipStreamSynchronize(ctx->stream));
+    return VOFE_OK;
+}
+
 int vofe_triangulate_candidates(vofe_ctx* ctx, const double* d_K, const double* d_pose, const float* d_cur_xy,
                                 const void* d_first_xy, int first_is_f64, const double* d_transform,
                                 int transform_dim, const uint8_t* d_flag_in, int n, double alpha_min,

@@ -116,6 +116,48 @@ __global__ __launch_bounds__(1024) void candidate_filter_kernel(const float2* cu
 }
 
 
+// ---- bootstrap pair filter (reference initialization.py:54-64, :69-70) ----------------------------------------
+//     good_old = good_old[status.flatten() == 1];  good_new = tracked_points[status.flatten() == 1]
+//     distances = np.sqrt(np.sum((good_new - good_old) ** 2, axis=2)).flatten()           # float32
+//     drop = np.where(distances < dist_threshold_move);  good_old, good_new = np.delete(.., drop, axis=0)
+// and, with flag = the RANSAC inlier mask and no distance rule, good_old[mask == 1] / good_new[mask == 1].
+// A pair goes when its distance is BELOW the threshold, so a NaN distance stays (the candidate filter above drops it).
+// Same single-block, order-keeping, in-place-safe compaction as candidate_filter_kernel.
+__global__ __launch_bounds__(1024) void pair_filter_kernel(const float2* nw, const uint8_t* __restrict__ flag, const float2* old,
+                                                           int n, float s_ge_move, float2* nw_out, float2* old_out,
+                                                           int* __restrict__ count_out) {
+    __shared__ int wave_count[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        bool keep = false;
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (i < n) {
+            a = nw[i];
+            b = old[i];
+            const float dx = a.x - b.x, dy = a.y - b.y;
+            const float s = dx * dx + dy * dy;
+            keep = flag[i] == 1 && !(s < s_ge_move);
+        }
+        const unsigned long long ballot = __ballot(keep);
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's loads have returned before anyone stores
+        __syncthreads();
+        int offset = base + __popcll(ballot & ((1ull << lane) - 1)), total = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int cnt = wave_count[k];
+            offset += k < wave ? cnt : 0;
+            total += cnt;
+        }
+        if (keep) { nw_out[offset] = a; old_out[offset] = b; }
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = base;
+}
+
+
 // ---- batched triangulation of matured candidates (reference continuous.py:450-485, 274-309) ---------------------
 //     for idx with new_landmarks[idx]:
 //         proj1 = K @ inv(Ti[:, idx].reshape(3, 4));  proj2 = K @ inv(pose)
@@ -369,6 +411,18 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
                                        dist_tri, d_tracked_out, d_first_out, d_transform_out, d_tri_out, d_count_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "candidate_filter launch");
+    return VOFE_OK;
+}
+
+int vofe_launch_pair_filter(vofe_ctx* ctx, const float* d_new_xy, const uint8_t* d_flag, const float* d_old_xy, int n,
+                            double dist_move, float* d_new_out, float* d_old_out, int* d_count_out) {
+    // numpy compares the float32 distances with the Python scalar in float32
+    const float s_move = square_threshold_ge<float>((float)dist_move);
+    hipLaunchKernelGGL(pair_filter_kernel, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const float2*>(d_new_xy), d_flag,
+                       reinterpret_cast<const float2*>(d_old_xy), n, s_move, reinterpret_cast<float2*>(d_new_out),
+                       reinterpret_cast<float2*>(d_old_out), d_count_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vofe_hip_fail(e, "pair_filter launch");
     return VOFE_OK;
 }
 

@@ -116,6 +116,8 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
                                  const float* d_existing_xy, int n_existing, const float* d_existing2_xy, int n_existing2,
                                  double threshold, uint8_t* d_mask);
+int vofe_launch_pair_filter(vofe_ctx* ctx, const float* d_new_xy, const uint8_t* d_flag, const float* d_old_xy, int n,
+                            double dist_move, float* d_new_out, float* d_old_out, int* d_count_out);
 int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const uint8_t* d_status, const void* d_first_xy,
                                  int first_is_f64, const double* d_transform, int tdim, int n, double dist_min,
                                  double dist_max, double dist_tri, float* d_tracked_out, void* d_first_out,

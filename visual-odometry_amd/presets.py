@@ -18,7 +18,8 @@ TRACKING_PRESETS = {
 }
 _BOOT = dict(maxLevel=0, criteria=(3, 30, 0.01), minEigThreshold=1e-4)
 BOOTSTRAP_PRESETS = {
-    "kitti": dict(maxCorners=1000, qualityLevel=0.01, minDistance=10, winSize=(11, 11), **_BOOT),
-    "parking": dict(maxCorners=1000, qualityLevel=0.01, minDistance=10, winSize=(11, 11), **_BOOT),
-    "malaga": dict(maxCorners=400, qualityLevel=0.01, minDistance=10, winSize=(41, 41), **_BOOT),
+    # dist_threshold_move: initialization.py:186-188; n_images: how many frames the bootstrap chains over (:180-182)
+    "kitti": dict(maxCorners=1000, qualityLevel=0.01, minDistance=10, winSize=(11, 11), dist_threshold_move=2, n_images=3, **_BOOT),
+    "parking": dict(maxCorners=1000, qualityLevel=0.01, minDistance=10, winSize=(11, 11), dist_threshold_move=0, n_images=7, **_BOOT),
+    "malaga": dict(maxCorners=400, qualityLevel=0.01, minDistance=10, winSize=(41, 41), dist_threshold_move=0, n_images=5, **_BOOT),
 }
