@@ -110,6 +110,8 @@ def parse_args(argv):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_streaming / pcie_inclusive / hard_motion")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test aid: every rank uses GPU 0 (rehearses the N-rank path on a one-GPU box; the value is no scaling result)")
     ap.add_argument("--stub", action="store_true",
                     help="test aid: CPU ranks over gloo with a stub step (exercises launcher, sharding, fold, JSON)")
     return ap.parse_args(argv)
@@ -120,7 +122,7 @@ def launch_ranks(args, argv):
     """Parent of `bench.py --gpus N`: N fresh child processes, one per GPU, started before this process has touched a
     GPU (it never does).  Child r gets RANK = LOCAL_RANK = r and binds device r.  Returns the exit code."""
     n = args.gpus
-    if not args.stub:
+    if not args.stub and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()                  # counts devices without initialising them
         if have < n:
@@ -197,6 +199,8 @@ def run_rank(args):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0                                    # rehearsal: the ranks share the one GPU of the box
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -204,7 +208,21 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the ranks exchange nothing but the barrier and two 8-byte reductions of the timing: RCCL as the launch contract
+        # says, gloo if RCCL cannot come up on this node (recorded in the line as "rendezvous")
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            x = torch.zeros(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(x)
+            torch.cuda.synchronize()
+        except Exception as e:                                           # noqa: BLE001
+            print("bench.py rank %d: RCCL did not come up (%s); using gloo for the barrier" % (rank, str(e).splitlines()[0][:200]),
+                  file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    fold_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else None
 
     from visual_odometry_amd import _lib
     from visual_odometry_amd.frontend import FrontEnd, Pyramid
@@ -354,7 +372,7 @@ def run_rank(args):
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
     tsum = float(sum(tracked[i % NPH] for i in range(total_sets)))
     frames_rank = float(total_sets * B)
-    elapsed, (tsum, frames_total) = replicas.fold(dist, dev, elapsed, [tsum, frames_rank])
+    elapsed, (tsum, frames_total) = replicas.fold(dist, fold_dev or dev, elapsed, [tsum, frames_rank])
     fps = frames_total / elapsed
 
     out = None
@@ -427,6 +445,9 @@ def run_rank(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": scaling,
+            "rendezvous": (dist.get_backend() if dist is not None else "none"),
+            **({"rehearsal": "%d ranks share one GPU (--share-gpu): launcher / sharding / fold exercised, not a scaling figure" % world}
+               if args.share_gpu else {}),
             "vs_baseline": None,
             "dtype": "u8/int32 bilinear + int64 window sums, f32 2x2 solve",
             "data": "synthetic (seeded band-limited texture, KITTI-like warp + N(0,1.5) noise; SURVEY 8d)",
