@@ -191,7 +191,16 @@ __global__ __launch_bounds__(64) void triangulate_kernel(const double* __restric
                                                          const float2* __restrict__ cur, const F* __restrict__ first,
                                                          const double* __restrict__ transform, int tdim,
                                                          const uint8_t* __restrict__ flag_in, int n, double alpha_min,
-                                                         uint8_t* __restrict__ flag_out, double* __restrict__ xyz) {
+                                                         uint8_t* __restrict__ flag_out, double* __restrict__ xyz,
+                                                         const float2* __restrict__ copy_src, float2* __restrict__ copy_dst, int copy_n,
+                                                         int tri_blocks) {
+    if ((int)blockIdx.x >= tri_blocks) {
+        // rider of the frame-state object's phase 2: the surviving landmarks, which the host compacted into pinned memory
+        // that this device addresses, are fetched by these extra blocks instead of by a copy command in front of the launch
+        const int c = ((int)blockIdx.x - tri_blocks) * 64 + (int)threadIdx.x;
+        if (c < copy_n) copy_dst[c] = copy_src[c];
+        return;
+    }
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     if (!flag_in[i]) { flag_out[i] = 0; return; }
@@ -442,17 +451,24 @@ int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int 
 
 int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const VofePoseK* h_pk, const float* d_cur_xy,
                             const void* d_first_xy, int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in,
-                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz) {
-    if (n == 0) return VOFE_OK;
-    const dim3 grid((n + 63) / 64), block(64);
+                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz, const float* copy_src, float* copy_dst,
+                            int copy_n) {
+    if (!copy_src || !copy_dst || copy_n < 0) copy_n = 0;
+    if (n == 0 && copy_n == 0) return VOFE_OK;
+    const int tri_blocks = (n + 63) / 64;
+    const dim3 grid(tri_blocks + (copy_n + 63) / 64), block(64);
     VofePoseK pk;
     if (h_pk) { pk = *h_pk; d_K = nullptr; d_pose = nullptr; } else memset(&pk, 0, sizeof(pk));
+    const float2* cs = reinterpret_cast<const float2*>(copy_src);
+    float2* cd = reinterpret_cast<float2*>(copy_dst);
     if (first_is_f64)
         hipLaunchKernelGGL(triangulate_kernel<double>, grid, block, 0, ctx->stream, d_K, d_pose, pk, reinterpret_cast<const float2*>(d_cur_xy),
-                           static_cast<const double*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
+                           static_cast<const double*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz,
+                           cs, cd, copy_n, tri_blocks);
     else
         hipLaunchKernelGGL(triangulate_kernel<float>, grid, block, 0, ctx->stream, d_K, d_pose, pk, reinterpret_cast<const float2*>(d_cur_xy),
-                           static_cast<const float*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz);
+                           static_cast<const float*>(d_first_xy), d_transform, tdim, d_flag_in, n, alpha_min, d_flag_out, d_xyz,
+                           cs, cd, copy_n, tri_blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "triangulate launch");
     return VOFE_OK;

@@ -35,7 +35,8 @@ struct vofe_framestate {
     float* d_feat;                 // (max_corners, 2) detections of the frame
     uint8_t* d_fmask;              // (max_corners)
     uint8_t* d_par;                // phase 2: 192 B unused (pose and K travel as kernel arguments) | surviving landmarks (capP, 2) f32
-    uint8_t* h_par;                // pinned source of d_par
+    uint8_t* h_par;                // pinned source of d_par, mapped into the device (d_par_host): phase 2 fetches it from a kernel
+    uint8_t* d_par_host;
     // results in mapped pinned memory
     uint8_t *h_res, *d_res;
     size_t o_cnt, o_newP, o_newX;  // byte offsets of the counters / promoted landmarks in the result buffer
@@ -169,7 +170,8 @@ int vofe_framestate_create(int device, const vofe_framestate_params* params, vof
     FS_TRY(hipMalloc((void**)&fs->d_fmask, (size_t)p.max_corners));
     FS_TRY(hipMalloc((void**)&fs->d_par, 192 + capP * 8));
     FS_TRY(hipHostMalloc((void**)&fs->h_stage, px, hipHostMallocDefault));
-    FS_TRY(hipHostMalloc((void**)&fs->h_par, 192 + capP * 8, hipHostMallocDefault));
+    FS_TRY(hipHostMalloc((void**)&fs->h_par, 192 + capP * 8, hipHostMallocMapped));
+    FS_TRY(hipHostGetDevicePointer((void**)&fs->d_par_host, fs->h_par, 0));
     // results: tracked xy (8 B) | err (4 B) | status (1 B) per tracked point, then counters, promoted xy, promoted xyz
     fs->o_cnt = (ncap * 13 + 63) / 64 * 64;
     fs->o_newP = fs->o_cnt + 64;
@@ -320,17 +322,18 @@ int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, cons
     }
     // One stream: cross-stream events cost more host time here than overlapping the two independent kernels gains
     // (measured: update 41 -> 51 us with the de-duplication on the detector stream).  Pose and intrinsics travel as
-    // kernel arguments; the only upload is the list of surviving landmarks.
+    // kernel arguments; the list of surviving landmarks is read from mapped pinned memory by the first launch.
     VofePoseK pk;
     memcpy(pk.pose, h_pose, sizeof(pk.pose));
     memcpy(pk.K, p.K, sizeof(pk.K));
     float* d_P = reinterpret_cast<float*>(fs->d_par + 192);
-    if (m1) {
+    // (the surviving landmarks ride along with the triangulation launch: extra blocks fetch them from the mapped pinned
+    // buffer instead of a copy command in front of the kernels: update 41-45 -> 38-39 us)
+    if (m1 || K1) {
         rc = vofe_launch_triangulate(fs->c_trk, nullptr, nullptr, &pk, fs->d_C, fs->d_F, p.first_is_f64, fs->d_T, 12, fs->d_tri, m1,
-                                     p.thr_alpha_rad, fs->d_prom, fs->d_xyz);
+                                     p.thr_alpha_rad, fs->d_prom, fs->d_xyz, reinterpret_cast<const float*>(fs->d_par_host + 192), d_P, K1);
         if (rc) return rc;
     }
-    if (K1) VOFE_HIP(hipMemcpyAsync(d_P, P1, (size_t)K1 * 8, hipMemcpyHostToDevice, fs->s_trk));
     if (nf) {
         rc = vofe_new_feature_mask2(fs->c_trk, fs->d_feat, nf, fs->d_C, m1, d_P, K1, p.thr_new_keypoints, fs->d_fmask);
         if (rc) return rc;

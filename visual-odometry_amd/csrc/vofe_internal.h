@@ -127,7 +127,8 @@ int vofe_launch_candidate_filter(vofe_ctx* ctx, const float* d_tracked_xy, const
 struct VofePoseK { double pose[12]; double K[9]; };
 int vofe_launch_triangulate(vofe_ctx* ctx, const double* d_K, const double* d_pose, const VofePoseK* h_pk, const float* d_cur_xy,
                             const void* d_first_xy, int first_is_f64, const double* d_transform, int tdim, const uint8_t* d_flag_in,
-                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz);
+                            int n, double alpha_min, uint8_t* d_flag_out, double* d_xyz,
+                            const float* copy_src = nullptr, float* copy_dst = nullptr, int copy_n = 0);
 int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first_is_f64, double* d_T, int tdim, int m, int cap_c,
                                  const uint8_t* d_promote, const double* d_xyz, const float* d_features, const uint8_t* d_fmask,
                                  int nf, const double* d_pose, const VofePoseK* h_pk, float* d_P, int k, int cap_p, float* d_track_next,
