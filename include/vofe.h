@@ -50,7 +50,7 @@ int vofe_create(int device, void* hip_stream, vofe_ctx** out);
 int vofe_destroy(vofe_ctx* ctx);
 int vofe_synchronize(vofe_ctx* ctx);
 /* The VOFE_* environment switches (kernel-path overrides for tests and measurements: VOFE_LK, VOFE_PYRAMID,
- * VOFE_PAD_COPY, VOFE_CORNER_SCORE, VOFE_SCORE_RS, VOFE_NMS_ROWS, VOFE_GFTT_SORT, VOFE_GFTT_CHAIN, VOFE_GFTT_DEBUG, VOFE_SEL_*) are read once, by
+ * VOFE_PAD_COPY, VOFE_PYR_BORDERS, VOFE_CORNER_SCORE, VOFE_SCORE_RS, VOFE_NMS_ROWS, VOFE_GFTT_SORT, VOFE_GFTT_CHAIN, VOFE_GFTT_DEBUG, VOFE_SEL_*) are read once, by
  * vofe_create; this re-reads them for an existing context (test aid; no counterpart in the reference). */
 int vofe_reload_env(vofe_ctx* ctx);
 

@@ -291,9 +291,13 @@ __device__ __forceinline__ int refl1(int c, int n) {      // one reflection is e
     return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c);
 }
 
+// band_w / band_h > 0: the block also writes the REFLECT_101 border bands (band_w columns left and right, band_h rows above
+// and below, corners included) whose SOURCE pixels it owns -- every border pixel mirrors exactly one interior pixel, so the
+// owners' scattered copies cover the bands without a second launch.  Needs band_w <= w - 1 and band_h <= h - 1 on every level
+// (one reflection); the host falls back to pyramid_borders otherwise.
 __global__ __launch_bounds__(1024) void pyramid_fused(const uint8_t* __restrict__ src, int spitch, size_t img_stride,
                                                      const VofeLevel* __restrict__ lv, FusePlan P, int slot0,
-                                                     int with_deriv) {
+                                                     int with_deriv, int band_w, int band_h) {
     extern __shared__ uint8_t R[];
     const int T = P.levels - 1;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = (int)blockDim.x >> 5;
@@ -395,6 +399,27 @@ __global__ __launch_bounds__(1024) void pyramid_fused(const uint8_t* __restrict_
                     *reinterpret_cast<unsigned*>(drow + x) = v;
                 } else {
                     for (int q = x; q < ox1; ++q) drow[q] = row[q];
+                }
+            }
+            if (band_w > 0) {
+                // rows this source row lands in: itself, its mirror above the image, its mirror below it
+                const int xl1 = min(ox1 - 1, band_w), xr0 = max(ox0, L.w - 1 - band_w), xr1 = min(ox1 - 1, L.w - 2);
+                for (int q = 0; q < 3; ++q) {
+                    int yt = y;
+                    if (q == 1) { if (y < 1 || y > band_h) continue; yt = -y; }
+                    if (q == 2) { if (y < L.h - 1 - band_h || y > L.h - 2) continue; yt = 2 * (L.h - 1) - y; }
+                    uint8_t* trow = L.I + so + (long long)yt * L.pitch;
+                    if (q)
+                        for (int x = ox0 + tx * 4; x < ox1; x += 128) {
+                            if (x + 4 <= ox1) {
+                                const unsigned v = (unsigned)row[x] | ((unsigned)row[x + 1] << 8) | ((unsigned)row[x + 2] << 16) | ((unsigned)row[x + 3] << 24);
+                                *reinterpret_cast<unsigned*>(trow + x) = v;
+                            } else {
+                                for (int c = x; c < ox1; ++c) trow[c] = row[c];
+                            }
+                        }
+                    for (int x = max(ox0, 1) + tx; x <= xl1; x += 32) trow[-x] = row[x];
+                    for (int x = xr0 + tx; x <= xr1; x += 32) trow[2 * (L.w - 1) - x] = row[x];
                 }
             }
             if (with_deriv) {
@@ -550,7 +575,7 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     const bool small = (long long)pyr->height * pyr->width * count <= 2000000ll;      // measured cross-over
     const bool fused = force ? force == 'f' : small;
     if (pyr->levels <= FUSE_MAX_LEVELS && fused) {
-        // fused path: 2 launches (interiors + Scharr, then border bands)
+        // fused path: one launch (interiors + Scharr + border bands), or two when a level is too small for that
         FusePlan P;
         P.levels = pyr->levels;
         const int T = P.levels - 1;
@@ -565,12 +590,17 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         const VofeLevel& Lt = pyr->lv[T];
         dim3 grid((Lt.w + P.tw - 1) / P.tw, (Lt.h + P.th - 1) / P.th, count);
         if (grid.y > 65535) { vofe_set_error("pyramid: image too tall"); return VOFE_E_UNSUPPORTED; }
+        // the border bands in the same launch when one reflection reaches them on every level (the owners of the source
+        // pixels scatter them); VOFE_PYR_BORDERS=separate or VOFE_PAD_COPY=generic keep the second launch (tests, A/B)
+        const int band_w = 16 * ((ww + 15) / 16);
+        bool own_bands = !ctx->knobs.pyr_borders_separate && !ctx->knobs.pad_copy_generic;
+        for (int l = 0; l < pyr->levels; ++l) own_bands = own_bands && pyr->lv[l].w >= band_w + 17 && pyr->lv[l].h >= wh + 1;
         {
         VOFE_TIMED(ctx, "pyramid_fused");
         hipLaunchKernelGGL(pyramid_fused, grid, dim3(1024), (size_t)off, st, d_img, pitch, img_stride, pyr->d_lv, P, slot0,
-                           pyr->with_deriv);
+                           pyr->with_deriv, own_bands ? band_w : 0, own_bands ? wh : 0);
         }
-        launch_borders(ctx, pyr, 0, slot0, count, st);
+        if (!own_bands) launch_borders(ctx, pyr, 0, slot0, count, st);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");
         return VOFE_OK;
