@@ -165,7 +165,28 @@ def generate_sequences(ids, h, w, n_frames):
 
 
 # ------------------------------------------------------------------------------------------------ one rank
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner and gloo its connection lines to stdout when
+    a process group comes up: from here on file descriptor 1 is stderr for everything (Python and native libraries), and
+    emit_result() writes the line to the real stdout."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_result(obj):
+    out = _RESULT_OUT if _RESULT_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def run_rank(args):
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -487,7 +508,7 @@ def run_rank(args):
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit_result(out)
     return 0
 
 
@@ -721,11 +742,11 @@ def run_stub(args, rank, world, B, scaling, my_ids):
     elapsed = time.perf_counter() - t0
     elapsed, (frames_total, id_sum) = replicas.fold(d, torch.device("cpu"), elapsed, [float(total_sets * B), float(sum(my_ids))])
     if rank == 0:
-        print(json.dumps({"metric": "frames/sec (stub)", "value": round(frames_total / elapsed, 2), "unit": "frames/s",
+        emit_result({"metric": "frames/sec (stub)", "value": round(frames_total / elapsed, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
                           "stub": True, "frames_total": frames_total, "sequence_id_sum": id_sum,
-                          "sequences_rank0": my_ids[:4], "sequences_per_rank": B}), flush=True)
+                     "sequences_rank0": my_ids[:4], "sequences_per_rank": B})
     if d is not None:
         d.barrier()
         d.destroy_process_group()
