@@ -492,12 +492,13 @@ def run_rank(args):
             "attempted_points_per_s": round(frames_total * n / elapsed, 1),
             "roofline": roof,
         }
-        if not args.no_extras:
+        # the figures beside the headline belong to the N = 1 line (the CPU baseline is timed on rank 0 at N = 1 only)
+        if not args.no_extras and world == 1:
             out["roofline_streaming"] = streaming_rooflines(torch, fe, _lib, Pyramid, phases[0][0], H, W)
             out["pcie_inclusive"] = pcie_inclusive(fe, frames, pts_host[0], H, W, n)
             out["hard_motion"] = hard_motion(torch, fe, _lib, Pyramid, H, W, n, min(B, 64), d_cnt)
         out["verified"] = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(phases[0][2], gpu_phase0, n, args.cpu_seconds)
             out["verified"] = out["cpu_baseline"].pop("verified")
     for wk in workers:
