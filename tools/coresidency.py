@@ -19,7 +19,9 @@ B = 64
 L = _lib.load()
 dev = torch.device("cuda", 0)
 fr = synthetic.sequence(H, W, seed, 2)
-sT, sP = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+PRIO = int(os.environ.get("COR_PRIO", "0"))      # -1: the side stream gets the high priority
+sT, sP = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=PRIO)
+print("side stream priority", PRIO, "range", torch.cuda.Stream.priority_range())
 feT, feP = FrontEnd(0, stream=sT), FrontEnd(0, stream=sP)
 c = feT.goodFeaturesToTrack(fr[0], n, 0.01, 7)
 pts = synthetic.pad_points(c, n, H, W, seed)
