@@ -1313,6 +1313,24 @@ def test_bootstrap_tracker_argument_and_order_errors(fe):
         BootstrapTracker(97, 131, frontend=fe, maxCorners=0)
 
 
+# ------------------------------------------------------------------ a C host on the C ABI
+def test_c_host_program_runs_the_frame_loop_against_ground_truth():
+    """examples/frame_loop.c: a C99 program that links libvofe.so and nothing else drives vofe_framestate over 23 frames of
+    a textured plane under a known camera translation; it checks the tracked flows against the known image motion and
+    the depth of every promoted candidate against the plane, and prints 'frame_loop ok'."""
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "frame_loop")
+    if not os.path.exists(exe):
+        exe = g.build_example()                       # (gcc, one second: not a HIP build)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and "frame_loop ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("promoted")][0]
+    assert int(last.split()[1]) >= 50 and " 0 off the plane" in last, last
+
+
 # ------------------------------------------------------------------ real textures (SURVEY 8c item 5, load-if-present)
 _REAL_DIR = "/opt/conda/lib/python3.9/site-packages/skimage/data"
 

@@ -88,3 +88,11 @@ def test_synthetic_is_seeded():
     assert a[0].dtype == np.uint8 and a[0].shape == (40, 50) and a[0].std() > 20
     p = synthetic.pad_points(None, 100, 40, 50, 1)
     assert p.shape == (100, 2) and p.dtype == np.float32
+
+
+def test_c_host_example_compiles_as_c99_and_links():
+    """include/vofe.h is plain C (gcc -std=c99 -pedantic -Werror) and every entry point the C host program uses resolves
+    against libvofe.so; the program itself runs in the GPU suite."""
+    import __graft_entry__ as g
+    exe = g.build_example()
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
