@@ -62,6 +62,8 @@ def _bench(*argv, env=None):
 def _line(proc):
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     assert proc.returncode == 0 and len(lines) == 1, (proc.returncode, proc.stdout, proc.stderr[-2000:])
+    # the contract is ONE line on stdout: the process-group banners (gloo here, RCCL on GPUs) go to stderr
+    assert proc.stdout.strip() == lines[0], proc.stdout
     return json.loads(lines[0])
 
 
