@@ -96,3 +96,21 @@ def test_c_host_example_compiles_as_c99_and_links():
     import __graft_entry__ as g
     exe = g.build_example()
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+def test_build_refuses_kernels_that_spill_to_scratch():
+    """build.py reads the compiler's per-kernel resource remarks and refuses a library in which any kernel uses scratch
+    memory (the parser, on the remark format of this toolchain)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vofe_build", os.path.join(ROOT, "visual-odometry_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    text = """lk.hip:1050:1: remark: Function Name: _ZN12_GLOBAL__N_118lk_track_kernel_x2ILi2EEEvNS_6LKArgsE [-Rpass-analysis=kernel-resource-usage]
+lk.hip:1050:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]
+lk.hip:1050:1: remark:     ScratchSize [bytes/lane]: 128 [-Rpass-analysis=kernel-resource-usage]
+lk.hip:431:1: remark: Function Name: other_kernel [-Rpass-analysis=kernel-resource-usage]
+lk.hip:431:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+"""
+    rep = b.scratch_report(text)
+    assert rep == {"_ZN12_GLOBAL__N_118lk_track_kernel_x2ILi2EEEvNS_6LKArgsE": 128, "other_kernel": 0}
+    assert b.scratch_report("") == {}

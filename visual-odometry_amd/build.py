@@ -19,11 +19,39 @@ def build_lib(force=False, verbose=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", out] + [os.path.join(csrc, s) for s in SOURCES]
+    # The same compile reports every kernel's resources; a kernel that spills registers to scratch memory is refused: none
+    # of the shipped kernels needs scratch, and the one experimental build that did (the two-keypoint tracker forced to 128
+    # VGPRs) faulted the GPU (profiles/r02_overlap_experiments.txt).
+    tmp = out                    # (compiled in place: the offload bundle embeds an id derived from the output name)
+    cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", tmp] + [os.path.join(csrc, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    report = scratch_report(r.stderr)
+    other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln and ln.strip()]
+    if other:
+        print("\n".join(other))
+    if r.returncode:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    bad = {k: v for k, v in report.items() if v}
+    if bad:
+        os.remove(tmp)
+        raise RuntimeError("kernels that spill to scratch memory (bytes per lane): %r" % bad)
+    if not report:
+        os.remove(tmp)
+        raise RuntimeError("the compiler reported no kernel resources: cannot check for scratch use")
     return out
+
+
+def scratch_report(stderr_text):
+    """{kernel name: scratch bytes per lane} from -Rpass-analysis=kernel-resource-usage remarks."""
+    rep, name = {}, None
+    for ln in stderr_text.splitlines():
+        if "Function Name:" in ln:
+            name = ln.split("Function Name:")[1].split("[")[0].strip()
+        elif "ScratchSize [bytes/lane]:" in ln and name is not None:
+            rep[name] = max(rep.get(name, 0), int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0].strip()))
+    return rep
 
 
 if __name__ == "__main__":
