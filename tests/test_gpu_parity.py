@@ -1291,6 +1291,29 @@ def test_pair_filter_c_abi_numpy_decisions_nan_in_place(fe):
     assert b"vofe_pair_filter" in L.vofe_last_error()
 
 
+def test_bootstrap_tracker_device_frames_and_restart(fe):
+    """Frames that are already on the device (torch tensors) take the copy path instead of the staged upload; detect()
+    on a tracker that has been used starts a new bootstrap: both give the oracle's pairs."""
+    import torch
+    from visual_odometry_amd import BOOTSTRAP_PRESETS
+    from visual_odometry_amd.bootstrap import BootstrapTracker
+    params = dict(BOOTSTRAP_PRESETS["parking"])
+    frames = _seq(240, 320, 77, 4)
+    keep_all = lambda gn, go: np.ones((len(gn), 1), np.uint8)             # noqa: E731
+    ro, rn, steps = oracle.bootstrap_correspondences(frames[1:], params, keep_all)
+    bt = BootstrapTracker(240, 320, frontend=fe, **params)
+    bt.detect(frames[0])
+    bt.track(frames[3])                                                      # some other bootstrap first
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    bt.detect(dev[1])
+    for i in (2, 3):
+        go, gn = bt.track(dev[i])
+        assert np.array_equal(go, steps[i - 2][0]) and np.array_equal(gn, steps[i - 2][1]), i
+        bt.keep(keep_all(gn, go))
+    go, gn = bt.pairs()
+    assert np.array_equal(go, ro) and np.array_equal(gn, rn) and len(ro) > 50
+
+
 def test_bootstrap_tracker_argument_and_order_errors(fe):
     from visual_odometry_amd import error
     from visual_odometry_amd.bootstrap import BootstrapTracker
