@@ -799,6 +799,18 @@ template <int PPW> struct Cfg {
 
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+// Two window pixels per register.  `pair` holds a value in its low half; the result keeps that half and takes
+// (src >> sh) & 0xffff as its high half: the arithmetic shift every bilinear sample ends with, done by the SDWA form of the
+// shift so that it deposits its result in the upper word -- packing two differences costs no instruction beyond the two
+// shifts they need anyway, and the sums of products b1 / b2 then take one v_dot2 per pixel PAIR instead of one multiply-add
+// per pixel.  (`sh` lives in a register: SDWA takes no literal.)
+__device__ __forceinline__ int shr_into_high_half(int pair, int src, int sh) {
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(pair) : "v"(sh), "v"(src));
+    return pair;
+}
+constexpr int RP = (R + 1) / 2;          // register pairs per strip (the last one holds a single row)
+
 // exact sum over the lanes of a group (one or two DPP rows), result in every lane of the group
 template <int PPW>
 __device__ __forceinline__ int half_sum(int v, int partner_addr) {
@@ -912,10 +924,12 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         // shifts).  (Pairing pixels for v_dot2 in the b1 / b2 sums was measured slower: v_dot2 is half rate.)
         // Ix and Iy stay in separate registers: v_mad_i32_i24 (4 cycles) per product instead of an SDWA multiply
         // plus a share of a 3-operand add.
-        int Cval[NS][R], IXv[NS][R], IYv[NS][R];
+        int Cval[NS][R];
+        unsigned IXp[NS][RP], IYp[NS][RP];              // (Ix[2q] | Ix[2q+1] << 16), (Iy[2q] | Iy[2q+1] << 16); upper half 0 past the strip
         float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
+            const int fourteen = 14;
             const gbase_t Ib = plane_base(A.I, A.pitch);
             const gbase_t Db = (gbase_t)((const uint8_t*)A.D - 4 * ((long long)W * A.pitch + PADX));
             const unsigned tbase = (unsigned)slotA * (unsigned)A.slot_stride + (unsigned)((ipy + W) * A.pitch + ipx + PADX);
@@ -939,11 +953,24 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
-                    const int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
-                    const int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
                     Cval[s][k] = 256 - (iv << 9);
-                    IXv[s][k] = ix; IYv[s][k] = iy;
-                    a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                }
+#pragma unroll
+                for (int qd = 0; qd < RP; ++qd) {
+                    // |Ix|, |Iy| <= 4080: two rows per register (the odd row's shift deposits it in the upper half), and the
+                    // structure tensor by pairs as well
+                    const int k = 2 * qd;
+                    int xp = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
+                    int yp = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                    if (k + 1 < R) {
+                        xp = shr_into_high_half(xp, sdot2(pX[k + 1], dw0, sdot2(pX[k + 2], dw1, 8192)), fourteen);
+                        yp = shr_into_high_half(yp, sdot2(pY[k + 1], dw0, sdot2(pY[k + 2], dw1, 8192)), fourteen);
+                    } else {
+                        xp &= 0xffff; yp &= 0xffff;             // a lone last row: nothing above it
+                    }
+                    IXp[s][qd] = (unsigned)xp; IYp[s][qd] = (unsigned)yp;
+                    a11 = sdot2((unsigned)xp, (unsigned)xp, a11); a12 = sdot2((unsigned)xp, (unsigned)yp, a12);
+                    a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
                 }
             }
             if (partials_fit(a11, a12, a22)) {
@@ -971,6 +998,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             stage_write<PPW>(pre, region, l32);
             lds_order();
         }
+        const int nine = 9;
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = floor_i(npx), iny = floor_i(npy);
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
@@ -992,10 +1020,13 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #pragma unroll
                 for (int r = 0; r <= R; ++r) P[r] = lp[r * RS];
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const int diff = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[s][k])) >> 9;
-                    b1 += diff * IXv[s][k];
-                    b2 += diff * IYv[s][k];
+                for (int qd = 0; qd < RP; ++qd) {
+                    const int k = 2 * qd;
+                    int dp = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[s][k])) >> 9;        // |diff| <= 8160: a half register
+                    if (k + 1 < R) dp = shr_into_high_half(dp, sdot2(P[k + 1], q.w0, sdot2(P[k + 2], q.w1, Cval[s][k + 1])), nine);
+                    // (a lone last row leaves its sign extension in the upper half: the template's upper half is 0 there)
+                    b1 = sdot2((unsigned)dp, IXp[s][qd], b1);
+                    b2 = sdot2((unsigned)dp, IYp[s][qd], b2);
                 }
             }
             float fb1, fb2;
