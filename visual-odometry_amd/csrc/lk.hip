@@ -61,6 +61,16 @@ __device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), c, false);
 }
 
+// Two window pixels per register.  `pair` holds a value in its low half; the result keeps that half and takes
+// (src >> sh) & 0xffff as its high half: the arithmetic shift every bilinear sample ends with, done by the SDWA form of the
+// shift so that it deposits its result in the upper word -- packing two differences costs no instruction beyond the two
+// shifts they need anyway, and the sums of products b1 / b2 then take one v_dot2 per pixel PAIR instead of one multiply-add
+// per pixel.  (`sh` lives in a register: SDWA takes no literal.)
+__device__ __forceinline__ int shr_into_high_half(int pair, int src, int sh) {
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(pair) : "v"(sh), "v"(src));
+    return pair;
+}
 // exact wave-wide sum of one int32 per lane, as int64 (all 64 lanes must be active)
 __device__ __forceinline__ int row_sum16(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
@@ -277,7 +287,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             }
         }
         // ---- template window: I, Ix, Iy at the fixed prev position -> registers
-        int Ival[R], Dval[R];
+        constexpr int RP = (R + 1) / 2;              // rows in pairs, two per register (see shr_into_high_half)
+        int Cval[R];                                  // 256 - 512 * I: the seed that turns the bilinear J sample into J - I
+        unsigned IXp[RP], IYp[RP];                    // (Ix[2q] | Ix[2q+1] << 16), (Iy[2q] | Iy[2q+1] << 16)
         float fA11, fA12, fA22;
         {
             const Wts q = bilinear_weights(ppx, ppy, ipx, ipy);
@@ -302,15 +314,27 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             // rows a lane does not own must contribute Ix = Iy = 0.  With the regular mapping (WC) a lane owns
             // all R rows or none, so zero weights do it: (0 + 8192) >> 14 == 0.
             const unsigned dw0 = (REG && ny == 0) ? 0u : q.w0, dw1 = (REG && ny == 0) ? 0u : q.w1;
+            const int fourteen = 14;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
-                int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
-                int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
-                if (!REG && k >= ny) { ix = 0; iy = 0; }
-                Ival[k] = iv;
-                Dval[k] = (ix & 0xffff) | (iy << 16);
-                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                Cval[k] = 256 - (iv << 9);
+            }
+#pragma unroll
+            for (int qd = 0; qd < RP; ++qd) {
+                const int k = 2 * qd;
+                int xp = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;      // |Ix|, |Iy| <= 4080: half a register each
+                int yp = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                if (!REG && k >= ny) { xp = 0; yp = 0; }
+                if (k + 1 < R && (REG || k + 1 < ny)) {
+                    xp = shr_into_high_half(xp, sdot2(pX[k + 1], dw0, sdot2(pX[k + 2], dw1, 8192)), fourteen);
+                    yp = shr_into_high_half(yp, sdot2(pY[k + 1], dw0, sdot2(pY[k + 2], dw1, 8192)), fourteen);
+                } else {
+                    xp &= 0xffff; yp &= 0xffff;            // no row above this one (or not this lane's)
+                }
+                IXp[qd] = (unsigned)xp; IYp[qd] = (unsigned)yp;
+                a11 = sdot2((unsigned)xp, (unsigned)xp, a11); a12 = sdot2((unsigned)xp, (unsigned)yp, a12);
+                a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
             }
             if (partials_fit(a11, a12, a22)) {
                 fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
@@ -339,6 +363,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             __syncthreads();
         }
         STAMP_END(2);
+        const int nine = 9;
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = floor_i(npx), iny = floor_i(npy);
             if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
@@ -361,11 +386,13 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                const int diff = jv - Ival[k];
-                b1 += diff * (int)(short)Dval[k];
-                b2 += diff * (Dval[k] >> 16);
+            for (int qd = 0; qd < RP; ++qd) {
+                const int k = 2 * qd;
+                int dp = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[k])) >> 9;          // J - I, |.| <= 8160: half a register
+                if (k + 1 < R) dp = shr_into_high_half(dp, sdot2(P[k + 1], q.w0, sdot2(P[k + 2], q.w1, Cval[k + 1])), nine);
+                // (rows without a partner, or not this lane's, meet a zero half in IXp / IYp)
+                b1 = sdot2((unsigned)dp, IXp[qd], b1);
+                b2 = sdot2((unsigned)dp, IYp[qd], b2);
             }
             STAMP_END(3);
             float fb1, fb2;
@@ -412,8 +439,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             int se = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                const int diff = jv - Ival[k];
+                const int diff = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[k])) >> 9;
                 se += (REG || k < ny) ? abs(diff) : 0;
             }
             if (REG && ny == 0) se = 0;
@@ -540,7 +566,10 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
     const uint8_t* J0 = B.I + (long long)slotB * B.slot_stride;
     bool staged = false, eig_ok = false;
     int rx0 = 0, ry0 = 0;
-    int Ival[R], Dval[R];
+    constexpr int RP = (R + 1) / 2;                  // rows in pairs, two per register (see shr_into_high_half)
+    int Cval[R];
+    unsigned IXp[RP], IYp[RP];
+    const int nine = 9, fourteen = 14;
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, Dd = 0.f;
     if (in_bounds) {
         StageRegs pre;
@@ -575,12 +604,23 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int iv = sdot2(pI[k], q.w0, sdot2(pI[k + 1], q.w1, 256)) >> 9;
-                int ix = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
-                int iy = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
-                if (!REG && k >= ny) { ix = 0; iy = 0; }
-                Ival[k] = iv;
-                Dval[k] = (ix & 0xffff) | (iy << 16);
-                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                Cval[k] = 256 - (iv << 9);
+            }
+#pragma unroll
+            for (int qd = 0; qd < RP; ++qd) {
+                const int k = 2 * qd;
+                int xp = sdot2(pX[k], dw0, sdot2(pX[k + 1], dw1, 8192)) >> 14;
+                int yp = sdot2(pY[k], dw0, sdot2(pY[k + 1], dw1, 8192)) >> 14;
+                if (!REG && k >= ny) { xp = 0; yp = 0; }
+                if (k + 1 < R && (REG || k + 1 < ny)) {
+                    xp = shr_into_high_half(xp, sdot2(pX[k + 1], dw0, sdot2(pX[k + 2], dw1, 8192)), fourteen);
+                    yp = shr_into_high_half(yp, sdot2(pY[k + 1], dw0, sdot2(pY[k + 2], dw1, 8192)), fourteen);
+                } else {
+                    xp &= 0xffff; yp &= 0xffff;
+                }
+                IXp[qd] = (unsigned)xp; IYp[qd] = (unsigned)yp;
+                a11 = sdot2((unsigned)xp, (unsigned)xp, a11); a12 = sdot2((unsigned)xp, (unsigned)yp, a12);
+                a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
             }
             if (partials_fit(a11, a12, a22)) {
                 fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
@@ -643,11 +683,12 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
                         for (int r = 0; r <= R; ++r) P[r] = lp[LK_ROW(r) * rs];
                         int b1 = 0, b2 = 0;
 #pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                            const int diff = jv - Ival[k];
-                            b1 += diff * (int)(short)Dval[k];
-                            b2 += diff * (Dval[k] >> 16);
+                        for (int qd = 0; qd < RP; ++qd) {
+                            const int k = 2 * qd;
+                            int dp = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[k])) >> 9;
+                            if (k + 1 < R) dp = shr_into_high_half(dp, sdot2(P[k + 1], q.w0, sdot2(P[k + 2], q.w1, Cval[k + 1])), nine);
+                            b1 = sdot2((unsigned)dp, IXp[qd], b1);
+                            b2 = sdot2((unsigned)dp, IYp[qd], b2);
                         }
                         float fb1, fb2;
                         if (partials_fit(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
@@ -690,8 +731,7 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
                             int se = 0;
 #pragma unroll
                             for (int k = 0; k < R; ++k) {
-                                const int jv = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, 256)) >> 9;
-                                const int diff = jv - Ival[k];
+                                const int diff = sdot2(P[k], q.w0, sdot2(P[k + 1], q.w1, Cval[k])) >> 9;
                                 se += (REG || k < ny) ? abs(diff) : 0;
                             }
                             if (REG && ny == 0) se = 0;
@@ -799,16 +839,6 @@ template <int PPW> struct Cfg {
 
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// Two window pixels per register.  `pair` holds a value in its low half; the result keeps that half and takes
-// (src >> sh) & 0xffff as its high half: the arithmetic shift every bilinear sample ends with, done by the SDWA form of the
-// shift so that it deposits its result in the upper word -- packing two differences costs no instruction beyond the two
-// shifts they need anyway, and the sums of products b1 / b2 then take one v_dot2 per pixel PAIR instead of one multiply-add
-// per pixel.  (`sh` lives in a register: SDWA takes no literal.)
-__device__ __forceinline__ int shr_into_high_half(int pair, int src, int sh) {
-    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-        : "+v"(pair) : "v"(sh), "v"(src));
-    return pair;
-}
 constexpr int RP = (R + 1) / 2;          // register pairs per strip (the last one holds a single row)
 
 // exact sum over the lanes of a group (one or two DPP rows), result in every lane of the group
