@@ -50,8 +50,9 @@ N_FRAMES = 8
 # SQ_INSTS_VALU, GRBM_GUI_ACTIVE (cycles) and FETCH_SIZE / WRITE_SIZE per launch of exactly this launch shape
 # (tools/pmc_workload.py under tools/pmc_passes.sh), keyed by (pairs per launch, points per pair).
 LK_PMC = {
-    (64, 2000): {"valu_instr": 651.0e6, "cycles": 22137155.0 / 8, "fetch_kb": 1725226.4, "write_kb": 6170.2,
-                 "source": "profiles/r02_pmc_inst.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r02_pmc_fetch.txt, r02_pmc_write.txt"},
+    # (the kernel with two window rows per register; before it: 651.0e6 instructions, 22137155 / 8 cycles, profiles/r02_pmc_inst.txt)
+    (64, 2000): {"valu_instr": 590664631.0, "cycles": 20955989.7 / 8, "fetch_kb": 1730305.2, "write_kb": 6231.0,
+                 "source": "profiles/r02_pmc_inst_v5.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r02_pmc_fetch_v5.txt, r02_pmc_write_v5.txt"},
 }
 
 
@@ -452,7 +453,10 @@ def run_rank(args):
                          "pmc_source": pmc["source"],
                          "mix_bound_note": "the kernel's instructions are mostly the half-rate class (v_dot2_i32_i16, "
                                            "v_mad_i32_i24, v_add3, DPP adds: 4.1-4.2 cycles each in isolation, "
-                                           "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD",
+                                           "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD; "
+                                           "the two-rows-per-register arithmetic took 9 % of the instructions out (5.09 k -> "
+                                           "4.61 k per keypoint) for 5 % of the cycles, which lowers this fraction while the "
+                                           "launch got faster",
                          "hbm": hbm})
         else:
             roof.update(hbm)
