@@ -429,7 +429,7 @@ def run_rank(args):
 
         alg_bytes = lk_algorithmic_bytes(WIN, float(cnt_launch[1]), float(cnt_launch[2]))
         hbm_achieved = alg_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
-        x2 = NB >= 4000
+        x2 = NB >= 3200                     # LK_X2_MIN_POINTS of csrc/lk.hip
         kname = "lk_track_kernel_x2<2> (two keypoints per wavefront)" if x2 else "lk_track_kernel<7, 21>"
         kernel = "%s: fwd + bwd + FB check of %d pairs x %d points in one launch" % (kname, B, n)
         pmc = LK_PMC.get((B, n))

@@ -229,7 +229,7 @@ __device__ __forceinline__ void stage_rest(unsigned* lds, const uint8_t* __restr
 // one wave per level pays while the extra waves find idle SIMDs: measured (tools/lp_sweep.sh, KITTI / Parking frames, fwd + bwd)
 // 300 points 38.2 -> 34.5 us, 500 points 39.2 -> 35.8 us, break-even near 1000 points (4 waves per SIMD), 30 % slower at 2000
 constexpr int LK_LP_MAX_POINTS = 640;
-constexpr int LK_X2_MIN_POINTS = 4000;     // measured (scratch/lk_threshold.py, lk_bench.py): one per wavefront 5 % ahead at 3000 points, two per wavefront 8 % ahead at 4000
+constexpr int LK_X2_MIN_POINTS = 3200;     // measured with the rows packed two per register (lk_bench.py, KITTI): equal to one per wavefront at 2000-3000 points, 7 % ahead at 3500, 11 % at 4000, 21 % at 6000
 constexpr int LK_NO_ERR = 1 << 16;     // internal flag: the backward pass of the FB check has no use for err
 
 // WC != 0: compile-time square window WC x WC, so window geometry, the LDS row stride and all row offsets fold
