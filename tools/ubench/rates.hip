@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void k(int* out, int n, int a0, int b0) {
         if (OP == 27) { REP8(asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r0) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r1) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r2) : "v"(a)); asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(r3) : "v"(a));) }
         if (OP == 28) { REP8(asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(r3) : "v"(a), "v"(b));) }
         if (OP == 29) { REP8(asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r0) : "v"(a), "v"(b), "v"(r4)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r1) : "v"(a), "v"(b), "v"(r5)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r2) : "v"(a), "v"(b), "v"(r6)); asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r3) : "v"(a), "v"(b), "v"(r7));) }
+        if (OP == 31) { REP8(asm volatile("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r0) : "v"(a), "v"(r4)); asm volatile("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r1) : "v"(a), "v"(r5)); asm volatile("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r2) : "v"(a), "v"(r6)); asm volatile("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r3) : "v"(a), "v"(r7));) }
+        if (OP == 32) { REP8(asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(r0) : "v"(r4)); asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(r1) : "v"(r5)); asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(r2) : "v"(r6)); asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(r3) : "v"(r7));) }
+        if (OP == 33) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r0) : "v"(a), "v"(b)); asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r1) : "v"(a), "v"(b)); asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r2) : "v"(a), "v"(b)); asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r3) : "v"(a), "v"(b));) }
         if (OP == 30) { REP8(asm volatile("v_mov_b32 %0, %1" : "=v"(r0) : "v"(r4)); asm volatile("v_mov_b32 %0, %1" : "=v"(r1) : "v"(r5)); asm volatile("v_mov_b32 %0, %1" : "=v"(r2) : "v"(r6)); asm volatile("v_mov_b32 %0, %1" : "=v"(r3) : "v"(r7));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = (int)(d0 + d1 + d2 + d3) + r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (int)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
@@ -91,5 +94,8 @@ int main() {
     run<28>("v_dot2_i32_i16 VOP3P acc", d, 32);
     run<29>("v_dot2_i32_i16 VOP3P seed", d, 32);
     run<30>("v_mov_b32", d, 32);
+    run<31>("v_ashrrev_i32_sdwa (into WORD_1, preserve)", d, 32);
+    run<32>("v_mov_b32_sdwa (WORD_0 -> WORD_1, preserve)", d, 32);
+    run<33>("v_perm_b32 (4 chains)", d, 32);
     return 0;
 }
