@@ -51,8 +51,41 @@ def lib():
         L.vofe_cpu_corner_score.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
         L.vofe_cpu_gftt.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p,
                                     C.c_int, C.c_double, f32p, C.c_int, i32p, C.c_int]
+        L.vofe_cpu_set_variant.argtypes = [C.c_int] * 6
         _LIB = L
     return _LIB
+
+
+# Alternative arithmetics for the cv2-build dependent points of SURVEY Appendix A (vofe_oracle.h, vofe_cpu_set_variant).
+# name -> keyword arguments of variant(); "canonical" is what the HIP kernels follow.
+LK_VARIANTS = {
+    "f32_raster": dict(lk_sum=1), "f32_lane4": dict(lk_sum=2), "f32_lane4_fma": dict(lk_sum=3),
+    "f32_ui128": dict(lk_sum=4), "f32_ui128_fma": dict(lk_sum=5), "f32_lane8": dict(lk_sum=6),
+    "f32_lane8_fma": dict(lk_sum=7),
+}
+SCORE_VARIANTS = {
+    "sobel_fma": dict(sobel=1), "sobel_scale_after": dict(sobel=2), "mineig_fma": dict(mineig_fma=1),
+    "box_running": dict(box_running=1), "thresh_ipp": dict(thresh_ipp=1),
+    "all_fma": dict(sobel=1, mineig_fma=1, box_running=1, thresh_ipp=1),
+}
+HARRIS_VARIANTS = {"harris_scalar_f64": dict(harris=1), "harris_vector_f32": dict(harris=2)}
+
+
+class variant:
+    """with oracle.variant(lk_sum=1): ...   -- runs the oracle with one of the alternative arithmetics, then restores the
+    canonical one.  Process-wide (the C++ side keeps it in a global): not for concurrent use."""
+
+    def __init__(self, lk_sum=0, sobel=0, mineig_fma=0, box_running=0, harris=0, thresh_ipp=0):
+        self.args = (lk_sum, sobel, mineig_fma, box_running, harris, thresh_ipp)
+
+    def __enter__(self):
+        if lib().vofe_cpu_set_variant(*self.args):
+            raise ValueError("unknown oracle variant %r" % (self.args,))
+        return self
+
+    def __exit__(self, *exc):
+        lib().vofe_cpu_set_variant(0, 0, 0, 0, 0, 0)
+        return False
 
 
 def _p(a, t):

@@ -12,6 +12,11 @@
  *    converted to f32 once;
  *  - float stages in the operation order stated at each function, built with -ffp-contract=off;
  *  - floor_i() maps non-finite / huge coordinates to INT_MIN so that they fail the bounds tests.
+ *
+ * VARIANTS (vofe_cpu_set_variant): every point SURVEY Appendix A marks as depending on the cv2
+ * binary's SIMD dispatch / IPP use has switchable alternatives here, so that tests can MEASURE how
+ * far the plausible cv2 arithmetics lie from the canonical one (tests/test_variants_cpu.py,
+ * DESIGN.md section 3).  Variant 0 is the canonical arithmetic and the only one the kernels follow.
  */
 #include "vofe_oracle.h"
 
@@ -37,6 +42,80 @@ inline int floor_i(float v) {                     // cvFloor with a defined resu
     return i - ((float)i > v);
 }
 inline int round_i(float v) { return (int)lrintf(v); }   // cvRound: half to even
+
+// ---------------------------------------------------------------- variants (SURVEY A.1, A.2, A.5 "⚠" points)
+struct Variant {
+    int lk_sum = 0;       // A.5 steps 4, 6.  0 exact int64 (canonical) | 1 f32 raster (scalar C++ build)
+                          // 2/3 four f32 lanes, 4 px per step, without/with FMA (the NEON loop's shape)
+                          // 4/5 universal-intrinsics 128-bit loop: 8 px per step into 4 lanes, A by muladd
+                          //     without/with FMA, b by int32 pair dot products converted to f32 (x86 wheel)
+                          // 6/7 eight f32 lanes, 8 px per step, without/with FMA (a 256-bit build)
+    int sobel = 0;        // A.1 step 2.  0 canonical | 1 FMA in the smoothing pass | 2 exact integer Sobel, scaled after (IPP-like)
+    int mineig_fma = 0;   // A.1 step 5.  sqrt argument as fma(b, b, (a-c)*(a-c))
+    int box_running = 0;  // A.1 step 4.  f64 box sums as OpenCV's running row / column sums instead of direct 3+3 sums
+    int harris = 0;       // A.1 step 5.  0 canonical f32 k*((a+c)^2) | 1 scalar path with k double | 2 f32 (k*(a+c))*(a+c)
+    int thresh_ipp = 0;   // A.2 step 2.  keep v unless v < (float)(thr + FLT_EPSILON)
+    bool any_lk() const { return lk_sum != 0; }
+};
+Variant g_variant;        // set between calls only (vofe_cpu_set_variant); worker threads read it
+
+// One f32 running sum of integer products in one of the orders a cv2 build may use.
+struct F32Acc {
+    int lanes = 1, step = 1;
+    bool fma = false;
+    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float tail = 0.f;
+    void init(int mode) {
+        switch (mode) {
+            case 2: case 3: lanes = 4; step = 4; break;
+            case 4: case 5: lanes = 4; step = 8; break;
+            case 6: case 7: lanes = 8; step = 8; break;
+            default: lanes = 1; step = 1; break;
+        }
+        fma = (mode == 3 || mode == 5 || mode == 7);
+    }
+    void add_row(const int* a, const int* b, int w) {
+        int x = 0;
+        if (lanes > 1)
+            for (; x <= w - step; x += step)
+                for (int s = 0; s < step; ++s) {
+                    float fa = (float)a[x + s], fb = (float)b[x + s];
+                    float& l = lane[s % lanes];
+                    l = fma ? fmaf(fa, fb, l) : l + fa * fb;
+                }
+        for (; x < w; ++x) tail += (float)(a[x] * b[x]);          // scalar loop: (itemtype)(int product), raster order
+    }
+    float total() const {
+        if (lanes == 1) return tail;
+        if (step == 4) return tail + (((lane[0] + lane[1]) + lane[2]) + lane[3]);   // stored to an array, summed left to right
+        float r = (lane[0] + lane[1]) + (lane[2] + lane[3]);                        // v_reduce_sum: pairwise
+        if (lanes == 8) r = r + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+        return tail + r;
+    }
+};
+// b1, b2 of the 128-bit universal-intrinsics loop: int32 dot products of pixel pairs (x, x+4), converted, f32 lanes.
+struct PairDotB {
+    float q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0}, t1 = 0.f, t2 = 0.f;
+    void add_row(const int* d, const int* ix, const int* iy, int w) {
+        int x = 0;
+        for (; x <= w - 8; x += 8) {
+            q0[0] += (float)(d[x] * ix[x] + d[x + 4] * ix[x + 4]);
+            q0[1] += (float)(d[x] * iy[x] + d[x + 4] * iy[x + 4]);
+            q0[2] += (float)(d[x + 1] * ix[x + 1] + d[x + 5] * ix[x + 5]);
+            q0[3] += (float)(d[x + 1] * iy[x + 1] + d[x + 5] * iy[x + 5]);
+            q1[0] += (float)(d[x + 2] * ix[x + 2] + d[x + 6] * ix[x + 6]);
+            q1[1] += (float)(d[x + 2] * iy[x + 2] + d[x + 6] * iy[x + 6]);
+            q1[2] += (float)(d[x + 3] * ix[x + 3] + d[x + 7] * ix[x + 7]);
+            q1[3] += (float)(d[x + 3] * iy[x + 3] + d[x + 7] * iy[x + 7]);
+        }
+        for (; x < w; ++x) { t1 += (float)(d[x] * ix[x]); t2 += (float)(d[x] * iy[x]); }
+    }
+    void totals(float& b1, float& b2) const {
+        float s0 = q0[0] + q1[0], s1 = q0[1] + q1[1], s2 = q0[2] + q1[2], s3 = q0[3] + q1[3];
+        b1 = t1 + ((s0 + s2) + (0.f + 0.f));
+        b2 = t2 + ((s1 + s3) + (0.f + 0.f));
+    }
+};
 
 template <class F>
 void parallel_for(int n, int nthreads, F&& body) {
@@ -180,9 +259,13 @@ inline Weights bilinear_weights(float fx, float fy, int ix, int iy) {
     return q;
 }
 
+template <bool VAR>
 void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float px, float py,
               float& nx, float& ny, uint8_t& status, float& err, std::vector<int16_t>& buf) {
     const int w = A.win_w, h = A.win_h;
+    const int vmode = VAR ? g_variant.lk_sum : 0;
+    std::vector<int> ra, rb, rc;                       // one window row of integer factors (variants only)
+    if (VAR) { ra.resize(w); rb.resize(w); rc.resize(w); }
     const float hx = (w - 1) * 0.5f, hy = (h - 1) * 0.5f;
     const int maxLevel = prev.max_level;
     buf.resize((size_t)3 * w * h);
@@ -210,6 +293,8 @@ void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float p
         }
         Weights q = bilinear_weights(ppx, ppy, ipx, ipy);
         int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+        F32Acc fA11, fA12, fA22;
+        if (VAR) { fA11.init(vmode); fA12.init(vmode); fA22.init(vmode); }
         for (int y = 0; y < h; ++y) {
             const uint8_t* s0 = I.row(ipy + y) + ipx;
             const uint8_t* s1 = I.row(ipy + y + 1) + ipx;
@@ -223,9 +308,12 @@ void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float p
                 dIp[2 * (y * w + x)] = (int16_t)ix;
                 dIp[2 * (y * w + x) + 1] = (int16_t)iy;
                 sA11 += (int64_t)ix * ix; sA12 += (int64_t)ix * iy; sA22 += (int64_t)iy * iy;
+                if (VAR) { ra[x] = ix; rb[x] = iy; }
             }
+            if (VAR) { fA11.add_row(ra.data(), ra.data(), w); fA12.add_row(ra.data(), rb.data(), w); fA22.add_row(rb.data(), rb.data(), w); }
         }
         float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        if (VAR) { A11 = fA11.total() * FLT_SCALE; A12 = fA12.total() * FLT_SCALE; A22 = fA22.total() * FLT_SCALE; }
         float Dd = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
         if (A.flags & 8) err = minEig;
@@ -244,6 +332,9 @@ void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float p
             }
             Weights r = bilinear_weights(npx, npy, inx, iny);
             int64_t sb1 = 0, sb2 = 0;
+            F32Acc fb1, fb2;
+            PairDotB pb;
+            if (VAR) { fb1.init(vmode); fb2.init(vmode); }
             for (int y = 0; y < h; ++y) {
                 const uint8_t* j0 = J.row(iny + y) + inx;
                 const uint8_t* j1 = J.row(iny + y + 1) + inx;
@@ -251,9 +342,18 @@ void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float p
                     int diff = descale(j0[x] * r.w00 + j0[x + 1] * r.w01 + j1[x] * r.w10 + j1[x + 1] * r.w11, W_BITS - 5) - Ip[y * w + x];
                     sb1 += (int64_t)diff * dIp[2 * (y * w + x)];
                     sb2 += (int64_t)diff * dIp[2 * (y * w + x) + 1];
+                    if (VAR) { ra[x] = diff; rb[x] = dIp[2 * (y * w + x)]; rc[x] = dIp[2 * (y * w + x) + 1]; }
+                }
+                if (VAR) {
+                    if (vmode == 4 || vmode == 5) pb.add_row(ra.data(), rb.data(), rc.data(), w);
+                    else { fb1.add_row(ra.data(), rb.data(), w); fb2.add_row(ra.data(), rc.data(), w); }
                 }
             }
             float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            if (VAR) {
+                if (vmode == 4 || vmode == 5) pb.totals(b1, b2); else { b1 = fb1.total(); b2 = fb2.total(); }
+                b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            }
             float dx = (A12 * b2 - A22 * b1) * Dd;
             float dy = (A12 * b1 - A11 * b2) * Dd;
             npx += dx; npy += dy;
@@ -297,11 +397,25 @@ void lk_criteria(int type, int& max_count, double& eps) {
 }
 
 // ---------------------------------------------------------------- corner score
+inline float score_from_cov(float c0, float c1, float c2, int harris, double k, const Variant& V) {
+    if (!harris) {
+        float a = c0 * 0.5f, b = c1, c = c2 * 0.5f;
+        float arg = V.mineig_fma ? fmaf(b, b, (a - c) * (a - c)) : (a - c) * (a - c) + b * b;
+        return (a + c) - std::sqrt(arg);
+    }
+    if (V.harris == 1)           // OpenCV's scalar loop: float products, k double
+        return (float)((double)(c0 * c2 - c1 * c1) - (k * (double)(c0 + c2)) * (double)(c0 + c2));
+    float kf = (float)k;
+    if (V.harris == 2)           // OpenCV's vector loop: (k*(a+c))*(a+c) in f32
+        return (c0 * c2 - c1 * c1) - (kf * (c0 + c2)) * (c0 + c2);
+    return (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2));
+}
+
 void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, double k, float* score, int nthreads) {
+    const Variant V = g_variant;
     const float s1 = (float)(1.0 / 3060.0), s2 = (float)(2.0 / 3060.0);
     std::vector<float> dx((size_t)h * w), dy((size_t)h * w);
     parallel_for(h, nthreads, [&](int y0, int y1) {
-        std::vector<float> ra(w), rb(w), rc(w);       // row-pass outputs of rows y-1,y,y+1
         for (int y = y0; y < y1; ++y) {
             const uint8_t* a = img + (size_t)reflect101(y - 1, h) * pitch;
             const uint8_t* b = img + (size_t)y * pitch;
@@ -310,14 +424,66 @@ void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, doubl
                 int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
                 // Dx: row kernel [-1 0 1] (exact), column kernel [s 2s s]
                 float r0 = (float)a[xp] - (float)a[xm], r1 = (float)b[xp] - (float)b[xm], r2 = (float)c[xp] - (float)c[xm];
-                dx[(size_t)y * w + x] = s2 * r1 + s1 * (r0 + r2);
                 // Dy: row kernel [s 2s s] on u8, column kernel [-1 0 1]
-                float q0 = s2 * (float)a[x] + s1 * (float)(a[xm] + a[xp]);
-                float q2 = s2 * (float)c[x] + s1 * (float)(c[xm] + c[xp]);
-                dy[(size_t)y * w + x] = q2 - q0;
+                float q0, q2;
+                if (V.sobel == 0) {
+                    dx[(size_t)y * w + x] = s2 * r1 + s1 * (r0 + r2);
+                    q0 = s2 * (float)a[x] + s1 * (float)(a[xm] + a[xp]);
+                    q2 = s2 * (float)c[x] + s1 * (float)(c[xm] + c[xp]);
+                    dy[(size_t)y * w + x] = q2 - q0;
+                } else if (V.sobel == 1) {       // muladd in the smoothing passes: f0*S0 first, then fma of the outer taps
+                    dx[(size_t)y * w + x] = fmaf(r0 + r2, s1, s2 * r1);
+                    q0 = fmaf((float)(a[xm] + a[xp]), s1, s2 * (float)a[x]);
+                    q2 = fmaf((float)(c[xm] + c[xp]), s1, s2 * (float)c[x]);
+                    dy[(size_t)y * w + x] = q2 - q0;
+                } else {                         // exact integer Sobel, one multiplication by the scale afterwards
+                    dx[(size_t)y * w + x] = (2.f * r1 + (r0 + r2)) * s1;
+                    int g = (2 * c[x] + c[xm] + c[xp]) - (2 * a[x] + a[xm] + a[xp]);
+                    dy[(size_t)y * w + x] = (float)g * s1;
+                }
             }
         }
     });
+    if (V.box_running) {
+        // OpenCV's boxFilter on the 3-channel product image: RowSum<float,double> (first 3 summed from 0, then
+        // s += S[i+3] - S[i] along the bordered row), ColumnSum<double,float> (SUM += row for the first two
+        // rows, then per output row s0 = SUM + new row; out = (float)s0; SUM = s0 - oldest row).  One stripe.
+        std::vector<double> rs((size_t)3 * h * w);
+        std::vector<float> br((size_t)3 * (w + 2));
+        for (int y = 0; y < h; ++y) {
+            for (int i = -1; i <= w; ++i) {
+                int sx = reflect101(i, w);
+                float gx = dx[(size_t)y * w + sx], gy = dy[(size_t)y * w + sx];
+                br[3 * (i + 1)] = gx * gx; br[3 * (i + 1) + 1] = gx * gy; br[3 * (i + 1) + 2] = gy * gy;
+            }
+            for (int ch = 0; ch < 3; ++ch) {
+                double sacc = 0;
+                for (int i = 0; i < 3; ++i) sacc += (double)br[3 * i + ch];
+                rs[((size_t)y * w) * 3 + ch] = sacc;
+                for (int x = 0; x < w - 1; ++x) {
+                    sacc += (double)br[3 * (x + 3) + ch] - (double)br[3 * x + ch];
+                    rs[((size_t)y * w + x + 1) * 3 + ch] = sacc;
+                }
+            }
+        }
+        std::vector<double> SUM((size_t)3 * w, 0.0);
+        auto rowp = [&](int y) { return rs.data() + (size_t)reflect101(y, h) * w * 3; };
+        for (int y = -1; y <= 0; ++y) { const double* Sp = rowp(y); for (int i = 0; i < 3 * w; ++i) SUM[i] += Sp[i]; }
+        for (int y = 0; y < h; ++y) {
+            const double* Sp = rowp(y + 1);
+            const double* Sm = rowp(y - 1);
+            for (int x = 0; x < w; ++x) {
+                float cc[3];
+                for (int ch = 0; ch < 3; ++ch) {
+                    double s0 = SUM[3 * x + ch] + Sp[3 * x + ch];
+                    cc[ch] = (float)s0;
+                    SUM[3 * x + ch] = s0 - Sm[3 * x + ch];
+                }
+                score[(size_t)y * w + x] = score_from_cov(cc[0], cc[1], cc[2], harris, k, V);
+            }
+        }
+        return;
+    }
     parallel_for(h, nthreads, [&](int y0, int y1) {
         for (int y = y0; y < y1; ++y) {
             for (int x = 0; x < w; ++x) {
@@ -337,15 +503,7 @@ void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, doubl
                 float c0 = (float)((rs0[0] + rs0[1]) + rs0[2]);
                 float c1 = (float)((rs1[0] + rs1[1]) + rs1[2]);
                 float c2 = (float)((rs2[0] + rs2[1]) + rs2[2]);
-                float out;
-                if (!harris) {
-                    float a = c0 * 0.5f, b = c1, c = c2 * 0.5f;
-                    out = (a + c) - std::sqrt((a - c) * (a - c) + b * b);
-                } else {
-                    float kf = (float)k;
-                    out = (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2));
-                }
-                score[(size_t)y * w + x] = out;
+                score[(size_t)y * w + x] = score_from_cov(c0, c1, c2, harris, k, V);
             }
         }
     });
@@ -355,6 +513,13 @@ void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, doubl
 
 // ================================================================= C ABI
 extern "C" {
+
+int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running, int harris, int thresh_ipp) {
+    if (lk_sum < 0 || lk_sum > 7 || sobel < 0 || sobel > 2 || harris < 0 || harris > 2) return -1;
+    g_variant.lk_sum = lk_sum; g_variant.sobel = sobel; g_variant.mineig_fma = !!mineig_fma;
+    g_variant.box_running = !!box_running; g_variant.harris = harris; g_variant.thresh_ipp = !!thresh_ipp;
+    return 0;
+}
 
 int vofe_cpu_pyr_down_u8(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch) {
     if (!src || !dst || h <= 0 || w <= 0) return -1;
@@ -413,7 +578,8 @@ int vofe_cpu_lk_track(const uint8_t* prev_img, const uint8_t* next_img, int h, i
             status[i] = 1;
             err[i] = 0.f;
             float nx = next_pts[2 * i], ny = next_pts[2 * i + 1];
-            lk_point(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
+            if (g_variant.any_lk()) lk_point<true>(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
+            else lk_point<false>(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
             next_pts[2 * i] = nx; next_pts[2 * i + 1] = ny;
         }
     });
@@ -470,7 +636,11 @@ int vofe_cpu_gftt(const uint8_t* img, int h, int w, int pitch, int max_corners, 
     if (!any) return 0;
     // 2. threshold to zero
     const float thr = (float)((double)maxv * quality);
-    for (auto& v : eig) v = v > thr ? v : 0.f;
+    if (g_variant.thresh_ipp) {                      // IPP-style TOZERO: v < thr + FLT_EPSILON -> 0
+        const float thr2 = thr + 1.1920928955078125e-07f;
+        for (auto& v : eig) v = v < thr2 ? 0.f : v;
+    } else
+        for (auto& v : eig) v = v > thr ? v : 0.f;
     // 3./4. 3x3 dilate + collect interior local maxima
     struct Cand { float v; int idx; };
     std::vector<Cand> cand;

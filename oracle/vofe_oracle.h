@@ -22,6 +22,16 @@
 extern "C" {
 #endif
 
+/* Selects one of the alternative arithmetics for the points SURVEY Appendix A marks as cv2-build dependent (all 0 =
+ * canonical, what the HIP kernels follow).  Process-wide, not thread-safe: set between calls.  Used only to measure
+ * how far the plausible cv2 arithmetics are from the canonical one (tests/test_variants_cpu.py).
+ *   lk_sum      A.5 steps 4/6: 0 exact int64 | 1 f32 raster | 2,3 4 lanes (w/o, with FMA) | 4,5 128-bit universal
+ *               intrinsics loop (8 px per step, pair dot products for b) | 6,7 8 lanes (w/o, with FMA)
+ *   sobel       A.1 step 2: 0 canonical | 1 FMA in the smoothing passes | 2 integer Sobel scaled afterwards
+ *   mineig_fma  A.1 step 5;  box_running  A.1 step 4 (running f64 sums);  harris  0 | 1 scalar double-k | 2 vector f32
+ *   thresh_ipp  A.2 step 2: v < thr + FLT_EPSILON -> 0 */
+int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running, int harris, int thresh_ipp);
+
 /* one pyrDown step, u8 -> u8, dst is ((w+1)/2, (h+1)/2). */
 int vofe_cpu_pyr_down_u8(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch);
 

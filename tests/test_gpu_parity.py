@@ -19,6 +19,47 @@ def _seq(h, w, seed, n=2):
     return synthetic.sequence(h, w, seed=seed, n_frames=n)
 
 
+# ------------------------------------------------------------------ committed golden data (not the live oracle)
+def test_hip_path_against_the_committed_golden_fixture(fe):
+    """tests/golden/frontend_small.npz holds inputs AND expected outputs (written once by make_golden.py from the oracle;
+    cv2 is absent).  Every other GPU test compares the kernels with the oracle as built today; this one compares
+    them with committed data, so kernels and oracle cannot drift together unnoticed on the GPU box.  No oracle call here."""
+    import os
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_small.npz"), allow_pickle=False)
+    a, b, pts = z["img0"], z["img1"], z["pts"]
+    pyr = Pyramid(fe, 1, a.shape[0], a.shape[1], (11, 11), 1, True)
+    pyr.build(torch.from_numpy(a).cuda(), 0)
+    lvl0, der0 = pyr.download(0, 0, deriv=True)
+    assert np.array_equal(lvl0, a) and np.array_equal(der0, z["scharr0"])
+    assert np.array_equal(pyr.download(0, 1), z["pyr1"])
+    pyr.free()
+    assert np.array_equal(fe.corner_score(a), z["score"])
+    assert np.array_equal(fe.corner_score(a, True), z["harris"])
+    assert np.array_equal(fe.goodFeaturesToTrack(a, 32, 0.01, 5), z["corners"])
+    n, s, e = fe.calcOpticalFlowPyrLK(a, b, pts, None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
+    assert np.array_equal(s, z["lk_status"])
+    ok = s.ravel() == 1
+    assert np.abs(n - z["lk_next"]).reshape(-1, 2)[ok].max() <= POS_TOL
+    assert np.array_equal(n, z["lk_next"]) and np.array_equal(e[ok], z["lk_err"][ok])
+    t, fs, fe_ = fe.track_keypoints(pts.T, a, b, (11, 11), 2)
+    assert np.array_equal(fs, z["fb_status"]) and np.array_equal(t, z["fb_next"])
+    assert np.array_equal(fe_[fs == 1], z["fb_err"][fs == 1])
+    # the canonical tracks of the second fixture (variants_small.npz holds the alternative arithmetics' outputs: the
+    # kernels must stay within the north-star bars of every one of them, as the CPU spread test shows for the oracle)
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "variants_small.npz"), allow_pickle=False)
+    t, fs, _ = fe.track_keypoints(v["pts"].T, v["img0"], v["img1"], (21, 21), 2)
+    for name in oracle.LK_VARIANTS:
+        vs, vt = v["lk_%s_status" % name], v["lk_%s_next" % name]
+        assert np.mean(vs == fs) >= STATUS_MIN, name
+        both = (vs == 1) & (fs == 1)
+        assert np.abs(vt - t)[:, both].max() <= POS_TOL, name
+    for name in oracle.SCORE_VARIANTS:
+        c = fe.goodFeaturesToTrack(v["img0"], 48, 0.01, 5)
+        assert set(map(tuple, c.reshape(-1, 2).tolist())) == set(map(tuple, v["corners_%s" % name].reshape(-1, 2).tolist())), name
+
+
 # ------------------------------------------------------------------ pyramid + Scharr (bit-exact)
 @pytest.mark.parametrize("h,w,win,levels", [(376, 1241, (21, 21), 3), (97, 131, (11, 11), 3),
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
