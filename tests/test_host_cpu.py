@@ -114,3 +114,30 @@ lk.hip:431:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-re
     rep = b.scratch_report(text)
     assert rep == {"_ZN12_GLOBAL__N_118lk_track_kernel_x2ILi2EEEvNS_6LKArgsE": 128, "other_kernel": 0}
     assert b.scratch_report("") == {}
+
+
+def test_isa_audit_finds_the_partial_write_hazard_and_the_wide_reload():
+    """tools/isa_audit.py is the build gate for the inline-assembly SDWA shift (build.py) and the aid of the spill study
+    (DESIGN.md section 8): it must flag a reader directly behind a partial register write, accept one behind a wait
+    state, and flag a spill reload that runs under a wider EXEC region than its store."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    sdwa = "\tv_ashrrev_i32_sdwa v5, v1, v2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+    n, sites = audit.hazard_sites(sdwa + "\tv_dot2_i32_i16 v7, v5, v9, v7\n")
+    assert n == 1 and len(sites) == 1
+    n, sites = audit.hazard_sites(sdwa + "\tv_dot2c_i32_i16_e32 v5, v8, v9\n")          # destination is read too
+    assert len(sites) == 1
+    n, sites = audit.hazard_sites(sdwa + "\tv_add_u32_e32 v6, v3, v4\n\tv_dot2_i32_i16 v7, v5, v9, v7\n")
+    assert n == 1 and not sites
+    n, sites = audit.hazard_sites(sdwa + "\ts_nop 0\n\tv_dot2_i32_i16 v7, v5, v9, v7\n")
+    assert not sites
+    n, sites = audit.hazard_sites(sdwa + "\tv_pk_add_f32 v[10:11], v[4:5], v[6:7]\n")     # register range
+    assert len(sites) == 1
+    kern = ("\nk:\n\ts_and_saveexec_b64 s[4:5], vcc\n\tscratch_store_dword off, v3, off offset:8\n\ts_or_b64 exec, exec, s[4:5]\n"
+            "\tscratch_load_dword v3, off, off offset:8\n\t.end_amdhsa_kernel\n")
+    out, bad = audit.spill_report(kern, "k")
+    assert bad == 1 and len(out) == 2
+    kern_ok = kern.replace("\ts_or_b64 exec, exec, s[4:5]\n\tscratch_load", "\tscratch_load") 
+    assert audit.spill_report(kern_ok, "k")[1] == 0

@@ -28,7 +28,9 @@ def build_lib(force=False, verbose=False):
         print(" ".join(cmd))
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
     report = scratch_report(r.stderr)
-    other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln and ln.strip()]
+    other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln and ln.strip()
+             and "'-dot4-insts' is not a recognized feature" not in ln       # the host pass ignores the device feature flag
+             and not ln.lstrip().startswith("|") and not (ln.split("|")[0].strip().isdigit() and "|" in ln)]
     if other:
         print("\n".join(other))
     if r.returncode:
@@ -40,7 +42,33 @@ def build_lib(force=False, verbose=False):
     if not report:
         os.remove(tmp)
         raise RuntimeError("the compiler reported no kernel resources: cannot check for scratch use")
+    sites = sdwa_hazard_sites(hipcc, csrc)
+    if sites:
+        os.remove(tmp)
+        raise RuntimeError("lk.hip: a VALU instruction reads a register directly after the inline-assembly SDWA shift wrote "
+                           "half of it (no hardware interlock on gfx950); rebuild with -DLK_SDWA_NOP or reorder: %r" % (sites[:3],))
     return out
+
+
+def sdwa_hazard_sites(hipcc, csrc):
+    """The one hazard the compiler cannot guard for us: lk.hip's inline-assembly SDWA shift writes half a register, and on
+    the gfx940 family a directly following VALU reader of that register is not interlocked (LLVM adds the wait state only
+    for SDWA instructions it selected itself).  The tracker source is compiled once more, device side only, to assembly,
+    and every partial-write SDWA instruction's successor is checked (tools/isa_audit.py has the same check as a tool)."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(_HERE, "..", "tools", "isa_audit.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "lk.s")
+        flags = [f for f in FLAGS if f not in ("-fPIC", "-shared")]
+        subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", "-o", asm, os.path.join(csrc, "lk.hip")],
+                       check=True, stderr=subprocess.DEVNULL)
+        n, sites = audit.hazard_sites(open(asm).read())
+    if n == 0:
+        raise RuntimeError("lk.hip: no partial-write SDWA instruction found in the assembly: the hazard check looked at nothing")
+    return sites
 
 
 def scratch_report(stderr_text):

@@ -66,8 +66,18 @@ __device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
 // shift so that it deposits its result in the upper word -- packing two differences costs no instruction beyond the two
 // shifts they need anyway, and the sums of products b1 / b2 then take one v_dot2 per pixel PAIR instead of one multiply-add
 // per pixel.  (`sh` lives in a register: SDWA takes no literal.)
+// Hazard note (gfx940 family): a VALU instruction that reads a register directly after an SDWA instruction wrote PART of it
+// (dst_sel != DWORD) needs one wait state; LLVM inserts it for SDWA instructions it selected itself but cannot see into inline
+// assembly.  The build therefore checks the generated assembly (tools/isa_audit.py --hazard, run by build.py): no such
+// instruction may directly follow this one.  -DLK_SDWA_NOP appends the wait state to the assembly text instead (one s_nop per
+// packed pair, ~2 % of the iteration's instructions) should a future compiler schedule a reader there.
+#ifdef LK_SDWA_NOP
+#define LK_SDWA_TAIL "\n\ts_nop 0"
+#else
+#define LK_SDWA_TAIL ""
+#endif
 __device__ __forceinline__ int shr_into_high_half(int pair, int src, int sh) {
-    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" LK_SDWA_TAIL
         : "+v"(pair) : "v"(sh), "v"(src));
     return pair;
 }
@@ -1107,8 +1117,15 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 }
 }  // namespace x2
 
+// Diagnostic builds only (tools/diag_w4.sh, never the shipped library): -DLK_X2_WAVES_PER_EU=4 makes the compiler hold the
+// kernel at 128 VGPRs by spilling to scratch memory (DESIGN.md section 8 has what that build showed).
+#ifdef LK_X2_WAVES_PER_EU
+#define LK_X2_ATTR __attribute__((amdgpu_waves_per_eu(LK_X2_WAVES_PER_EU, LK_X2_WAVES_PER_EU)))
+#else
+#define LK_X2_ATTR
+#endif
 template <int PPW>
-__global__ __launch_bounds__(64) void lk_track_kernel_x2(LKArgs a) {
+__global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
     extern __shared__ unsigned lds[];
     constexpr int GL = x2::Cfg<PPW>::GL, NS = x2::Cfg<PPW>::NS;
     const int lane = threadIdx.x, l32 = lane & (GL - 1), half = lane / GL;
