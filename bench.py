@@ -10,12 +10,15 @@ so that the driver's --steps 20 times more than a second.  Inputs are resident i
 step goes through the C ABI (libvofe.so).
 
 Multi-GPU = replicas only (the reference's frame loop main.py:107-118 is strictly sequential, sequences are
-the only unit that shards).  `python bench.py --gpus N` starts N fresh rank processes itself, one per GPU, before
-anything touches a GPU; under torchrun (WORLD_SIZE set) the process is a rank already.  Rank r tracks sequences
-r, r + N, r + 2N, ... (s mod N assignment) of BASELINE configs[3]'s independent KITTI-shaped sequences (seed 100 + s),
---batch of them per launch set ("weak" scaling: per-GPU work is fixed; --total-sequences 64 shards a fixed 64 instead
-and reports "strong").  No collective on the data path; the process group carries the barrier and the fold of
-(max time, summed frames).
+the only unit that shards).  `python bench.py --gpus N` starts N fresh rank processes itself, one per GPU; the parent
+never imports torch or calls HIP (a process that has initialised the GPU must not exec on this pool; the device count
+comes from a throw-away child), and under torchrun (WORLD_SIZE set) the process is a rank already.  EVERY point of a
+scaling curve runs the same workload: by default BASELINE configs[1] on every rank (rank r tracks its own KITTI-shaped
+sequence, seed 0 when alone, 100 + r otherwise; per-GPU work fixed = "weak"); `--workload configs3` is BASELINE
+configs[3] at any N including 1: rank r tracks sequences r, r + N, r + 2N, ... (seed 100 + s), --batch of them per
+launch set (weak), or a fixed pool with --total-sequences 64 ("strong").  No collective on the data path; the process
+group carries the barrier and the fold of (max time, summed frames, verification flags).  Every rank checks one frame
+pair of its own launch set against the CPU oracle outside the timed region ("all_ranks_verified").
 
 Prints ONE JSON line on rank 0: metric / value (whole-job frames/s) / roofline (dominant kernel: the tracker launch,
 HIP-event timed on its own stream inside the timed region) / roofline_streaming (pyramid, Scharr and score-map kernels,
@@ -105,6 +108,9 @@ def parse_args(argv):
                     help="launch sets in flight per GPU (one ctx + HIP stream + pyramid object each); 1 = serial")
     ap.add_argument("--free-overlap", action="store_true",
                     help="do not order the tracker launches of different streams (they then share the CUs)")
+    ap.add_argument("--workload", choices=("configs1", "configs3"), default="configs1",
+                    help="configs1: BASELINE configs[1] on every rank (its own sequence; the headline); configs3: BASELINE "
+                         "configs[3], independent sequences sharded s mod N, --batch per GPU")
     ap.add_argument("--total-sequences", type=int, default=0,
                     help="> 0: shard this many sequences over the ranks (strong scaling, e.g. 64 = configs[3] as written); "
                          "0: --batch sequences per GPU (weak scaling)")
@@ -119,13 +125,25 @@ def parse_args(argv):
 
 
 # ------------------------------------------------------------------------------------------------ launcher
+def count_gpus_in_a_child():
+    """Visible GPUs, counted by a throw-away child process (torch.cuda.device_count() there): the parent stays free of
+    torch and HIP, so nothing in it can have initialised a GPU before it starts (fork + exec) the ranks."""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        sys.stderr.write("bench.py: could not count GPUs (%s)\n" % (r.stderr.strip().splitlines()[-1:] or ["no output"])[0])
+        return 0
+
+
 def launch_ranks(args, argv):
-    """Parent of `bench.py --gpus N`: N fresh child processes, one per GPU, started before this process has touched a
-    GPU (it never does).  Child r gets RANK = LOCAL_RANK = r and binds device r.  Returns the exit code."""
+    """Parent of `bench.py --gpus N`: N fresh child processes, one per GPU.  This process never imports torch and never
+    calls HIP (checked by the CPU tests through the flag handed to the ranks).  Child r gets RANK = LOCAL_RANK = r,
+    binds device r and exits with status 2 when that device does not exist.  Returns the exit code."""
     n = args.gpus
     if not args.stub and not args.share_gpu:
-        import torch
-        have = torch.cuda.device_count()                  # counts devices without initialising them
+        have = count_gpus_in_a_child()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible\n" % (n, have))
             return 2
@@ -136,7 +154,9 @@ def launch_ranks(args, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), VOFE_BENCH_CHILD="1")
+                   MASTER_PORT=str(port), VOFE_BENCH_CHILD="1",
+                   VOFE_BENCH_PARENT_GPU_MODULES=",".join(sorted(m for m in ("torch", "visual_odometry_amd", "oracle")
+                                                                 if m in sys.modules)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     pending = list(procs)
@@ -196,7 +216,7 @@ def run_rank(args):
     n, B = args.points, max(1, args.batch)
 
     # ---- which sequences this rank owns ------------------------------------------------------------------------
-    sharded = world > 1 or args.total_sequences > 0
+    sharded = args.workload == "configs3" or args.total_sequences > 0
     if args.total_sequences > 0:
         my_ids = replicas.shard(args.total_sequences, rank, world)          # strong: a fixed pool, s mod N
         scaling = "strong"
@@ -224,7 +244,8 @@ def run_rank(args):
     if args.share_gpu:
         local_rank = 0                                    # rehearsal: the ranks share the one GPU of the box
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -394,7 +415,12 @@ def run_rank(args):
     lk_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else 0.0
     tsum = float(sum(tracked[i % NPH] for i in range(total_sets)))
     frames_rank = float(total_sets * B)
-    elapsed, (tsum, frames_total) = replicas.fold(dist, fold_dev or dev, elapsed, [tsum, frames_rank])
+    # every rank checks the first frame pair of its own launch set 0 (outputs taken before the timed region) against the
+    # CPU oracle -- the checker, outside the timed region; rank 0 at N = 1 checks the whole set in the cpu_baseline leg
+    rank_ok = 1.0
+    if not args.no_cpu:
+        rank_ok = 1.0 if verify_pairs(phases[0][2][:1], gpu_phase0, n)["ok"] else 0.0
+    elapsed, (tsum, frames_total, ok_ranks) = replicas.fold(dist, fold_dev or dev, elapsed, [tsum, frames_rank, rank_ok])
     fps = frames_total / elapsed
 
     out = None
@@ -481,9 +507,10 @@ def run_rank(args):
                                    if sharded else
                                    ("BASELINE.json configs[1]: synthetic KITTI-shaped 1241x376 frame pairs, %d keypoints, "
                                     "21x21 window, 4 pyramid levels, criteria (30,0.01), minEig 1e-3, "
-                                    "reference-call-equivalent (both pyramids rebuilt per pair)" % n),
+                                    "reference-call-equivalent (both pyramids rebuilt per pair)%s" % (
+                                        n, "" if world == 1 else "; every rank runs this workload on its own sequence (seed 100 + rank)")),
                        "frames_per_launch_set": B, "launch_sets_per_step": SETS, "frames_per_step": B * SETS * world,
-                       "points": n, "sequences": B * world if sharded else 1, "streams_per_gpu": S,
+                       "points": n, "sequences": B * world if sharded else world, "streams_per_gpu": S,
                        "parallelism": "replicas only: sequences sharded s mod N over %d GPU(s), no collective on the data path; "
                                       "a launch set is %d independent frame pairs, %d launch sets in flight per GPU" % (world, B, S)},
             "timed_seconds": round(elapsed, 4),
@@ -502,6 +529,7 @@ def run_rank(args):
             out["pcie_inclusive"] = pcie_inclusive(fe, frames, pts_host[0], H, W, n)
             out["hard_motion"] = hard_motion(torch, fe, _lib, Pyramid, H, W, n, min(B, 64), d_cnt)
         out["verified"] = None
+        out["all_ranks_verified"] = None if args.no_cpu else bool(ok_ranks == world)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(phases[0][2], gpu_phase0, n, args.cpu_seconds)
             out["verified"] = out["cpu_baseline"].pop("verified")
@@ -674,25 +702,18 @@ def hard_motion(torch, fe, _lib, Pyramid, H, W, n, B, d_cnt):
             "motion": "22 x 9 px per frame translation + 1 % per frame zoom (flow 10-40 px), 5 % of every frame occluded, N(0,1.5) noise"}
 
 
-def cpu_baseline(pairs, gpu_phase0, n, seconds):
-    """The CPU oracle (a port of the OpenCV path, kind 'port') on this box's host cores, same workload, bounded sample.
-    Reported beside the GPU number, never the thing measured above.  Its first results double as the checker of the
-    run: every pair of launch set 0 of the GPU path is compared with the oracle's triple ("verified")."""
+def verify_pairs(pairs, gpu_phase0, n, threads=None):
+    """Frame pairs [(prev, next, pts)] = slots 0.. of launch set 0 of the GPU path (gpu_phase0 = its outputs, taken before
+    the timed region) against oracle.track_keypoints, pair by pair.  The checker: never timed, never shipped."""
     import oracle
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = threads or max(1, min(16, os.cpu_count() or 1))
     distinct = {}
     for k, (a, b, p) in enumerate(pairs):                      # configs[1] repeats its 7 pairs over the 64 slots
         distinct.setdefault((id(a), id(b), id(p)), (a, b, p, []))[3].append(k)
-    work = list(distinct.values())
-
-    def track(a, b, p, nthreads):
-        return oracle.track_keypoints(p.T, a, b, WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, nthreads)
-
-    # verification (untimed): GPU launch set 0 against the oracle, pair by pair
     g_nxt, g_st, g_err = gpu_phase0
     checked, exact, status_equal, max_dpos = 0, True, 1.0, 0.0
-    for a, b, p, slots in work:
-        t0_, s0_, e0_ = track(a, b, p, threads)
+    for a, b, p, slots in distinct.values():
+        t0_, s0_, e0_ = oracle.track_keypoints(p.T, a, b, WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, threads)
         for k in slots:
             o = k * n
             gs, gn, ge = g_st[o:o + n], g_nxt[o:o + n].T, g_err[o:o + n]
@@ -702,13 +723,30 @@ def cpu_baseline(pairs, gpu_phase0, n, seconds):
                 max_dpos = max(max_dpos, float(np.abs(gn - t0_)[:, ok].max()))
             exact = exact and np.array_equal(gs, s0_) and np.array_equal(gn, t0_) and np.array_equal(ge, e0_)
             checked += 1
-    verified = bool(status_equal >= 0.995 and max_dpos <= 0.05)
+    return {"ok": bool(status_equal >= 0.995 and max_dpos <= 0.05), "bit_exact": bool(exact), "pairs_checked": checked,
+            "min_status_agreement": round(status_equal, 6), "max_position_difference_px": max_dpos,
+            "what": "every frame pair of one launch set of the timed GPU path (outputs taken before the timed "
+                    "region) against oracle.track_keypoints; bars 99.5 % status, 0.05 px"}
+
+
+def cpu_baseline(pairs, gpu_phase0, n, seconds):
+    """The CPU oracle (a port of the OpenCV path, kind 'port') on this box's host cores, same workload, bounded sample.
+    Reported beside the GPU number, never the thing measured above.  The same oracle doubles as the checker of the
+    run: every pair of launch set 0 of the GPU path is compared with the oracle's triple ("verified")."""
+    import oracle
+    threads = max(1, min(16, os.cpu_count() or 1))
+    seen, work = set(), []
+    for a, b, p in pairs:
+        if (id(a), id(b), id(p)) not in seen:
+            seen.add((id(a), id(b), id(p)))
+            work.append((a, b, p))
+    verified = verify_pairs(pairs, gpu_phase0, n, threads)
 
     def run(nthreads, budget):
         done, t0 = 0, time.perf_counter()
         while True:
-            a, b, p, _ = work[done % len(work)]
-            track(a, b, p, nthreads)
+            a, b, p = work[done % len(work)]
+            oracle.track_keypoints(p.T, a, b, WIN, MAX_LEVEL, CRITERIA, MIN_EIG, 1.0, nthreads)
             done += 1
             dt = time.perf_counter() - t0
             if dt >= budget and done >= 3:
@@ -718,11 +756,7 @@ def cpu_baseline(pairs, gpu_phase0, n, seconds):
     return {"value": round(fps_mt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d LK frames of the same workload (oracle/vofe_oracle.cpp, std::thread over points)" % n_mt,
             "single_thread_value": round(fps_1, 3), "single_thread_sample_frames": n_1,
-            "host_cpu_count": os.cpu_count(),
-            "verified": {"ok": verified, "bit_exact": bool(exact), "pairs_checked": checked,
-                         "min_status_agreement": round(status_equal, 6), "max_position_difference_px": max_dpos,
-                         "what": "every frame pair of one launch set of the timed GPU path (outputs taken before the timed "
-                                 "region) against oracle.track_keypoints; bars 99.5 % status, 0.05 px"}}
+            "host_cpu_count": os.cpu_count(), "verified": verified}
 
 
 # ------------------------------------------------------------------------------------------------ stub rank (CPU test)
@@ -750,7 +784,8 @@ def run_stub(args, rank, world, B, scaling, my_ids):
         emit_result({"metric": "frames/sec (stub)", "value": round(frames_total / elapsed, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
-                          "stub": True, "frames_total": frames_total, "sequence_id_sum": id_sum,
+                          "stub": True, "frames_total": frames_total, "sequence_id_sum": id_sum, "workload": args.workload,
+                          "parent_gpu_modules": os.environ.get("VOFE_BENCH_PARENT_GPU_MODULES"),
                      "sequences_rank0": my_ids[:4], "sequences_per_rank": B})
     if d is not None:
         d.barrier()

@@ -76,6 +76,11 @@ def test_bench_launcher_starts_n_ranks_world2_gloo():
     assert out["frames_total"] == 2 * 3 * 4 * 8                      # both ranks' launch sets, summed by the fold
     assert out["sequence_id_sum"] == sum(range(16))                  # every sequence of the pool is owned exactly once
     assert out["value"] > 0 and out["higher_is_better"] is True
+    # the parent of the ranks must never have imported torch (or anything else that can initialise a GPU): a process that
+    # has touched the GPU must not exec on the GPU pool, and the parent forks + execs N ranks
+    assert out["parent_gpu_modules"] == "" and out["workload"] == "configs1"
+    out3 = _line(_bench("--gpus", "2", "--stub", "--steps", "3", "--sets", "4", "--batch", "8", "--workload", "configs3"))
+    assert out3["workload"] == "configs3" and out3["sequences_rank0"] == [0, 2, 4, 6] and out3["frames_total"] == 2 * 3 * 4 * 8
     # strong scaling: a fixed pool of 64 sequences (BASELINE configs[3] as written) over 2 ranks
     out = _line(_bench("--gpus", "2", "--stub", "--steps", "2", "--sets", "2", "--total-sequences", "64"))
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["sequences_per_rank"] == 32
@@ -107,4 +112,17 @@ def test_bench_refuses_more_gpus_than_visible():
         import pytest
         pytest.skip("two GPUs visible")
     p = _bench("--gpus", "2", "--steps", "1")
-    assert p.returncode != 0 and "GPU(s) are visible" in p.stderr
+    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr
+
+
+def test_bench_parent_is_free_of_torch_and_hip():
+    """bench.py's module level and its launcher import neither torch nor the product package nor the oracle: importing
+    the file and running the parent's code path up to the spawn leaves sys.modules without them (the device count comes
+    from a throw-away child)."""
+    code = ("import sys, runpy; sys.argv = ['bench.py']; m = runpy.run_path(%r, run_name='bench_module');"
+            "n = m['count_gpus_in_a_child'](); "
+            "bad = [k for k in ('torch', 'visual_odometry_amd', 'oracle') if k in sys.modules];"
+            "print('COUNT', n, 'BAD', bad)") % os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "BAD []" in r.stdout and "COUNT %d" % torch.cuda.device_count() in r.stdout, r.stdout
