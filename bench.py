@@ -52,11 +52,37 @@ N_FRAMES = 8
 # Counter figures of the tracker launch that cannot be read inside a run (rocprofv3 --pmc needs a run of its own):
 # SQ_INSTS_VALU, GRBM_GUI_ACTIVE (cycles) and FETCH_SIZE / WRITE_SIZE per launch of exactly this launch shape
 # (tools/pmc_workload.py under tools/pmc_passes.sh), keyed by (pairs per launch, points per pair).
+# Every entry names the kernel source it was measured on by content hash: when that file has changed since, the counter
+# figures are not printed as a roofline fraction ("pmc_stale": true, VALU frac null) until the passes are re-run.
 LK_PMC = {
     # (the kernel with two window rows per register; before it: 651.0e6 instructions, 22137155 / 8 cycles, profiles/r02_pmc_inst.txt)
     (64, 2000): {"valu_instr": 590664631.0, "cycles": 20955989.7 / 8, "fetch_kb": 1730305.2, "write_kb": 6231.0,
+                 "kernel_source": ("lk.hip", "3cf88250f762b881"),
                  "source": "profiles/r02_pmc_inst_v5.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r02_pmc_fetch_v5.txt, r02_pmc_write_v5.txt"},
 }
+# corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
+# instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
+SCORE_PMC = {
+    128: {"valu_instr": 73401216.0, "cycles": 2860728.7 / 8, "mix_bound_cycles_per_instr": 3.6,
+          "kernel_source": ("corners.hip", "b06d9bc5bf1a777c"),
+          "source": "profiles/r02_pmc_wait.txt, r02_pmc_inst_v5.txt (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs); "
+                    "mix: profiles/r03_score_kernel_experiments.txt"},
+}
+
+
+def source_hash(name):
+    """First 16 hex digits of the SHA-256 of a kernel source file (what the PMC tables are keyed to)."""
+    import hashlib
+    with open(os.path.join(ROOT, "visual-odometry_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_is_current(entry):
+    name, digest = entry["kernel_source"]
+    try:
+        return source_hash(name) == digest
+    except OSError:
+        return False
 
 
 def lk_algorithmic_bytes(win, point_levels, iterations):
@@ -468,7 +494,14 @@ def run_rank(args):
                        "well below the algorithmic bytes (SURVEY 8d: point-levels*(w+1)^2*5 + iterations*(w+1)^2); "
                        "traffic = PMC FETCH_SIZE + WRITE_SIZE, raw (narrow 2/8/12-byte gathers: no gfx950 correction "
                        "is calibrated for that access shape)"}
-        if pmc and lk_ms > 0:
+        if pmc and not pmc_is_current(pmc):
+            # the counter pass was made on another lk.hip: no fraction from it (re-run tools/pmc_passes.sh and update LK_PMC)
+            roof.update(hbm)
+            roof.update({"pmc_stale": True, "valu": {"bound": "valu", "achieved": None, "peak": VALU_PEAK_IPC, "frac": None,
+                                                     "unit": "VALU instr/cycle/SIMD", "measured_on": pmc["kernel_source"][1],
+                                                     "current_source": source_hash(pmc["kernel_source"][0])},
+                         "traffic": None})
+        elif pmc and lk_ms > 0:
             # the launch is bound by VALU issue: instructions and cycles per launch from the counter pass of this launch
             # shape (clock-free); the live HIP-event duration says what clock those cycles ran at in this run
             ipc = pmc["valu_instr"] / N_SIMD / pmc["cycles"]
@@ -583,6 +616,21 @@ def streaming_rooflines(torch, fe, _lib, Pyramid, imgs, H, W):
             gbs = b / (t * 1e-3) / 1e9
             e.update({"bound": "hbm", "algorithmic_bytes_per_launch": int(b), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                       "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        sp = SCORE_PMC.get(frames) if nm.startswith("corner_score") else None
+        if sp:
+            # the score map is bound by VALU issue, not by HBM: its own roofline beside the byte figure
+            if pmc_is_current(sp):
+                ipc = sp["valu_instr"] / N_SIMD / sp["cycles"]
+                e["valu"] = {"bound": "valu", "achieved": round(ipc, 4), "peak": VALU_PEAK_IPC, "frac": round(ipc / VALU_PEAK_IPC, 4),
+                             "unit": "VALU instr/cycle/SIMD", "valu_instructions_per_pixel": round(sp["valu_instr"] / (frames * H * W), 2),
+                             "mix_bound": round(1.0 / sp["mix_bound_cycles_per_instr"], 4),
+                             "frac_of_mix_bound": round(ipc * sp["mix_bound_cycles_per_instr"], 4),
+                             "note": "~100 of the 239 instructions per 4-pixel row step are half-rate class (OpenCV's f64 box sums and "
+                                     "their conversions, u8 -> f32, the rounded sqrt), so back-to-back issue would take 3.6 cycles per "
+                                     "instruction: at that bound the kernel would reach ~30 % of HBM peak, not 60 %",
+                             "pmc_source": sp["source"]}
+            else:
+                e["valu"] = {"bound": "valu", "achieved": None, "frac": None, "pmc_stale": True}
         out.append(e)
     return out
 
