@@ -255,7 +255,7 @@ def test_lk_ragged_compile_time_windows(fe, knob, win, kernel):
     assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
 
 
-@pytest.mark.parametrize("ppw", ["x1", "lp", "x2", "x4"])
+@pytest.mark.parametrize("ppw", ["x1", "lp", "x2", "x2p", "x4"])
 def test_lk_21x21_kernel_families(fe, knob, ppw):
     """The 21x21 kernel families, each forced on the same small inputs: one keypoint per wavefront (x1), one wavefront
     per pyramid level (lp: what small launches take by the size rule), several keypoints per wavefront (x2 / x4: what
@@ -713,7 +713,7 @@ def test_full_size_config_front_end_frame(fe, cfg, md):
     assert (d[sb.ravel() == 1] < 1.0).all()
 
 
-@pytest.mark.parametrize("kernel", ["x1", "x2", "x4"])
+@pytest.mark.parametrize("kernel", ["x1", "x2", "x2p", "x4"])
 def test_ragged_batch_of_sequences_in_one_launch(fe, knob, kernel):
     """configs[3] batching: B pairs in one pyramid object, points of all pairs in ONE launch with a per-point
     image index (ragged: different counts per pair, one pair with none) == the per-pair results."""
@@ -1499,7 +1499,7 @@ def test_randomised_lk_21x21_sweep_all_kernels(fe, knob):
         with np.errstate(all="ignore"):
             n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig, nthreads=8)
             t0 = oracle.track_keypoints(pts.T, a, b, (21, 21), lvl, crit, mineig, 1.0, 8)
-        for kern in ("x1", "lp", "x2", "x4"):
+        for kern in ("x1", "lp", "x2", "x2p", "x4"):
             knob("VOFE_LK", kern)
             n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (21, 21), lvl, crit, flags, mineig)
             assert np.array_equal(s0, s1), (case, kern, h, w, lvl)

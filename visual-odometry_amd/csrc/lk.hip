@@ -919,7 +919,11 @@ __device__ __forceinline__ void restage(unsigned* region, gbase_t Jb, unsigned s
     lds_order();
 }
 
-template <int PPW>
+// PRE: the search region's loads are issued before the template window is computed (both latencies overlap inside the
+// wavefront) at the price of the 12 staging registers being live across the template set-up -- 150 VGPRs = 3 wavefronts per
+// SIMD.  Without it the region is loaded after the minimum-eigenvalue test: 127 VGPRs = 4 wavefronts per SIMD, which hide the
+// latency ACROSS wavefronts instead (and a level that fails the test stages nothing).
+template <int PPW, bool PRE>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* region, int l32, int partner_addr,
@@ -973,7 +977,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             const gbase_t Ib = plane_base(A.I, A.pitch);
             const gbase_t Db = (gbase_t)((const uint8_t*)A.D - 4 * ((long long)W * A.pitch + PADX));
             const unsigned tbase = (unsigned)slotA * (unsigned)A.slot_stride + (unsigned)((ipy + W) * A.pitch + ipx + PADX);
-            if (staged) stage_load<PPW>(pre, Jb, jslot, B, rx0, ry0, l32);
+            if (PRE && staged) stage_load<PPW>(pre, Jb, jslot, B, rx0, ry0, l32);
             int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1035,6 +1039,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         float pdx = 0.f, pdy = 0.f;
         if (staged) {
             lds_order();
+            if (!PRE) stage_load<PPW>(pre, Jb, jslot, B, rx0, ry0, l32);
             stage_write<PPW>(pre, region, l32);
             lds_order();
         }
@@ -1124,7 +1129,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #else
 #define LK_X2_ATTR
 #endif
-template <int PPW>
+template <int PPW, bool PRE>
 __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
     extern __shared__ unsigned lds[];
     constexpr int GL = x2::Cfg<PPW>::GL, NS = x2::Cfg<PPW>::NS;
@@ -1162,7 +1167,7 @@ __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        x2::lk_one<PPW>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0,
+        x2::lk_one<PPW, PRE>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0,
                         sok, n_lv, n_it);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
@@ -1244,9 +1249,11 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
                        !(flags & 8) && !(force && force[0] != 'l');
     const size_t lp_lds = ((size_t)LK_LP_HAND + (size_t)a.n_levels * a.rs * a.rh) * 4;
     if (x2_ok && force && force[0] == 'x' && force[1] == '4')
-        hipLaunchKernelGGL(lk_track_kernel_x2<4>, dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
+        hipLaunchKernelGGL((lk_track_kernel_x2<4, true>), dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
+    else if (x2_ok && force && force[0] == 'x' && force[1] == '2' && force[2] == 'p')          // "x2p": the prefetching variant (3 waves per SIMD)
+        hipLaunchKernelGGL((lk_track_kernel_x2<2, true>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
-        hipLaunchKernelGGL(lk_track_kernel_x2<2>, dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+        hipLaunchKernelGGL((lk_track_kernel_x2<2, false>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (lp_ok && a.win_w == 21 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
         hipLaunchKernelGGL((lk_track_kernel_lp<7, 21>), dim3(a.n), dim3(64 * a.n_levels), lp_lds, st, a);
     else if (lp_ok && a.win_w == 11 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
