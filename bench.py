@@ -111,6 +111,11 @@ def streaming_algorithmic_bytes(name, h, w, win, max_level, frames):
     if name.startswith("pyr_down_u8 L"):
         k = int(name.split("L")[-1])
         return frames * (px[k - 1] + px[k])
+    if name.startswith("pyr_step L"):                   # level pipeline: pyrDown (k-1 -> k) + Scharr of level k-1 in one launch
+        k = int(name.split("L")[-1])
+        return frames * (px[k - 1] + px[k] + 5 * px[k - 1])
+    if name.startswith("scharr_deriv_s16x2 last"):       # the last level's Scharr pass alone
+        return frames * 5 * px[-1]
     if name.startswith("scharr_deriv"):
         return frames * 5 * sum(px)
     if name.startswith("pyramid_borders"):

@@ -65,18 +65,23 @@ def test_hip_path_against_the_committed_golden_fixture(fe):
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
                                             (33, 250, (5, 7), 2), (600, 800, (41, 41), 0), (23, 49, (21, 21), 0),
                                             (200, 333, (31, 17), 2)])
-@pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic", "fused-separate"])
+@pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic", "fused-separate", "levels-separate", "levels-unstepped"])
 def test_pyramid_and_scharr_bit_exact(fe, knob, h, w, win, levels, path):
     """Both build paths (one fused launch for small frames, per-level kernels for large ones), each with the
     divergence-free copy / border kernels where the levels are wide enough and with the any-width ones forced; the fused
     launch with the border bands written by the owners of their source pixels (default where every level is large enough
-    for one reflection) and with the bands left to the border kernel (VOFE_PYR_BORDERS=separate)."""
+    for one reflection) and with the bands left to the border kernel (VOFE_PYR_BORDERS=separate); likewise the per-level
+    pyrDown kernel, which writes the bands of the level it produces unless told to leave them to the border launch; the
+    default per-level path is the level pipeline (launch k = pyrDown to level k + Scharr of level k-1), "unstepped" the plain
+    sequence of the same kernels."""
     import torch
     knob("VOFE_PYRAMID", path.split("-")[0])
     if path.endswith("generic"):
         knob("VOFE_PAD_COPY", "generic")
     if path.endswith("separate"):
         knob("VOFE_PYR_BORDERS", "separate")
+    if path.endswith("unstepped"):
+        knob("VOFE_PYR_STEP", "0")                 # pyrDown launches with their own border bands, Scharr of every level afterwards
     from visual_odometry_amd.frontend import Pyramid
     imgs = _seq(h, w, seed=h + w, n=2)
     pyr = Pyramid(fe, 2, h, w, win, levels, True)

@@ -39,6 +39,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->score_rs = env_int("VOFE_SCORE_RS", 0);
     k->nms_rows = env_int("VOFE_NMS_ROWS", 0);
     k->pyr_borders_separate = env_is("VOFE_PYR_BORDERS", 's');
+    k->pyr_step_off = env_is("VOFE_PYR_STEP", '0');
     k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
     if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : (v[0] == 'r' ? 'r' : 0);

@@ -102,12 +102,26 @@ __global__ __launch_bounds__(256) void pad_copy_level0_wide(const uint8_t* __res
 // (two per side, on its interior rows): level 0 has its full border from pad_copy_level0, and every level
 // written here gets those columns from the threads that own columns 1, 2, w-3 and w-2.  The full border
 // bands of the new levels (LK and Scharr need them) are filled afterwards by one pyramid_borders launch.
-__global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, int slot0, int gpr, int items) {
-    const int it = blockIdx.x * 256 + threadIdx.x;
+// BANDS: the thread also writes the REFLECT_101 border bands (win_w columns left and right, win_h rows above and below,
+// corners included) whose SOURCE pixels it owns: every border pixel mirrors exactly one interior pixel (column x in 1..win_w
+// goes to -x, column x in w-1-win_w..w-2 to 2(w-1)-x, rows likewise), so a full group is stored once more byte-reversed at
+// the mirrored position and a row in a mirror range once more to the mirrored row -- no pyramid_borders launch behind the
+// chain.  Needs win_w <= w - 1 and win_h <= h - 1 on the written level (one reflection); the host checks.  A reversed
+// group may reach up to 7 bytes past the band: the plane's padding (>= win_w + 20 columns) absorbs that.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef u32x2v u32x2v_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ void store8u(uint8_t* p, unsigned a, unsigned b) {
+    u32x2v q; q.x = a; q.y = b;
+    *reinterpret_cast<__attribute__((address_space(1))) u32x2v_unaligned*>((__attribute__((address_space(1))) uint8_t*)p) = q;
+}
+
+template <bool BANDS>
+__device__ __forceinline__ void pyr_down_body(const VofeLevel& S, const VofeLevel& Dl, int slot0, int gpr, int items, int win_w, int win_h,
+                                              int it, int img) {
     if (it >= items) return;
     const int yp = it / gpr, g = it - yp * gpr;
     const int X0 = g * 8, Y0 = yp * 2;
-    const uint8_t* sp = S.I + (long long)(slot0 + (int)blockIdx.y) * S.slot_stride + 2 * X0 - 4;
+    const uint8_t* sp = S.I + (long long)(slot0 + img) * S.slot_stride + 2 * X0 - 4;
     unsigned acc[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 128;
@@ -146,57 +160,87 @@ __global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, in
             }
         }
     }
-    const int w = Dl.w;
+    const int w = Dl.w, h = Dl.h;
     const bool full = X0 + 8 <= w;
     const bool edge = X0 == 0 || X0 + 8 > w - 3;
+    const bool src_l = BANDS && X0 <= win_w;                   // holds a column of 1..win_w
+    const bool src_r = BANDS && X0 + 7 >= w - 1 - win_w;       // holds a column of w-1-win_w..w-2
+    uint8_t* plane = Dl.I + (long long)(slot0 + img) * Dl.slot_stride;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const int y = Y0 + o;
-        if (y >= Dl.h) break;
-        uint8_t* drow = Dl.I + (long long)(slot0 + (int)blockIdx.y) * Dl.slot_stride + (long long)y * Dl.pitch;
+        if (y >= h) break;
         unsigned out[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = acc[o][j] >> 8;
-        if (full) {
-            uint2 q;
-            q.x = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-            q.y = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-            *reinterpret_cast<uint2*>(drow + X0) = q;
-        }
-        if (edge) {
-            // Nearly every wavefront holds a thread at a row end (a 621-pixel row is 78 groups), so this path is as hot as
-            // the body: keep it to a handful of instructions.  Left end: columns 1 and 2 go to -1 and -2.  Right end:
-            // columns w-2 and w-3 go to w and w+1 (each is picked out of the owning group's eight outputs by a select
-            // chain).  A ragged last group stores its w - X0 valid bytes as 4 + 2 + 1.
-            if (X0 == 0) {
-                if (1 < w) drow[-1] = (uint8_t)out[1];
-                if (2 < w) drow[-2] = (uint8_t)out[2];
-            }
-            const int j2 = w - 2 - X0, j3 = w - 3 - X0;
-            unsigned v2 = out[0], v3 = out[0];
+        const unsigned qx = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+        const unsigned qy = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+        // destination rows: y itself and, with BANDS, its mirror images above the first / below the last image row
+        const int ny = 1 + ((BANDS && y >= 1 && y <= win_h) ? 1 : 0) + ((BANDS && y <= h - 2 && y >= h - 1 - win_h) ? 1 : 0);
+        for (int c = 0; c < ny; ++c) {
+            int yd = y;
+            if (c > 0) yd = (c == 1 && y >= 1 && y <= win_h) ? -y : 2 * (h - 1) - y;
+            uint8_t* drow = plane + (long long)yd * Dl.pitch;
+            if (full) *reinterpret_cast<uint2*>(drow + X0) = make_uint2(qx, qy);
+            if (BANDS) {
+                if (full) {
+                    const unsigned rx = __builtin_bswap32(qy), rw = __builtin_bswap32(qx);      // the group byte-reversed
+                    if (src_l) store8u(drow - X0 - 7, rx, rw);
+                    if (src_r) store8u(drow + 2 * (w - 1) - X0 - 7, rx, rw);
+                } else if (X0 < w) {
+                    // the ragged last group of a row (one thread per row): byte by byte
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { v2 = j2 == j ? out[j] : v2; v3 = j3 == j ? out[j] : v3; }
-            if ((unsigned)j2 < 8u) drow[w] = (uint8_t)v2;
-            if ((unsigned)j3 < 8u) drow[w + 1] = (uint8_t)v3;
-            if (!full && X0 < w) {
-                const int nv = w - X0;                                                // 1..7
-                uint8_t* dp = drow + X0;
-                int o0 = 0;
-                if (nv & 4) { *reinterpret_cast<unsigned*>(dp) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o0 = 4; }
-                if (nv & 2) {
-                    const unsigned lo = o0 ? out[4] : out[0], hi = o0 ? out[5] : out[1];
-                    *reinterpret_cast<unsigned short*>(dp + o0) = (unsigned short)(lo | (hi << 8));
+                    for (int j = 0; j < 8; ++j) {
+                        const int x = X0 + j;
+                        if (x < w) {
+                            drow[x] = (uint8_t)out[j];
+                            if (x >= 1 && x <= win_w) drow[-x] = (uint8_t)out[j];
+                            if (x <= w - 2 && x >= w - 1 - win_w) drow[2 * (w - 1) - x] = (uint8_t)out[j];
+                        }
+                    }
                 }
-                if (nv & 1) {
-                    const int jb = nv - 1;
-                    unsigned vb = out[0];
+                continue;
+            }
+            if (edge) {
+                // Nearly every wavefront holds a thread at a row end (a 621-pixel row is 78 groups), so this path is as hot as
+                // the body: keep it to a handful of instructions.  Left end: columns 1 and 2 go to -1 and -2.  Right end:
+                // columns w-2 and w-3 go to w and w+1 (each is picked out of the owning group's eight outputs by a select
+                // chain).  A ragged last group stores its w - X0 valid bytes as 4 + 2 + 1.
+                if (X0 == 0) {
+                    if (1 < w) drow[-1] = (uint8_t)out[1];
+                    if (2 < w) drow[-2] = (uint8_t)out[2];
+                }
+                const int j2 = w - 2 - X0, j3 = w - 3 - X0;
+                unsigned v2 = out[0], v3 = out[0];
 #pragma unroll
-                    for (int j = 1; j < 7; ++j) vb = jb == j ? out[j] : vb;
-                    dp[jb] = (uint8_t)vb;
+                for (int j = 1; j < 8; ++j) { v2 = j2 == j ? out[j] : v2; v3 = j3 == j ? out[j] : v3; }
+                if ((unsigned)j2 < 8u) drow[w] = (uint8_t)v2;
+                if ((unsigned)j3 < 8u) drow[w + 1] = (uint8_t)v3;
+                if (!full && X0 < w) {
+                    const int nv = w - X0;                                                // 1..7
+                    uint8_t* dp = drow + X0;
+                    int o0 = 0;
+                    if (nv & 4) { *reinterpret_cast<unsigned*>(dp) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o0 = 4; }
+                    if (nv & 2) {
+                        const unsigned lo = o0 ? out[4] : out[0], hi = o0 ? out[5] : out[1];
+                        *reinterpret_cast<unsigned short*>(dp + o0) = (unsigned short)(lo | (hi << 8));
+                    }
+                    if (nv & 1) {
+                        const int jb = nv - 1;
+                        unsigned vb = out[0];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) vb = jb == j ? out[j] : vb;
+                        dp[jb] = (uint8_t)vb;
+                    }
                 }
             }
         }
     }
+}
+
+template <bool BANDS>
+__global__ __launch_bounds__(256) void pyr_down_u8(VofeLevel S, VofeLevel Dl, int slot0, int gpr, int items, int win_w, int win_h) {
+    pyr_down_body<BANDS>(S, Dl, slot0, gpr, items, win_w, win_h, (int)blockIdx.x * 256 + (int)threadIdx.x, (int)blockIdx.y);
 }
 
 __device__ __forceinline__ unsigned byte_of(const unsigned* w, int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
@@ -210,16 +254,11 @@ struct ScharrPlan {
     int levels;
 };
 
-__global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __restrict__ lv, ScharrPlan plan, int slot0) {
-    int level = 0;
-    while (level + 1 < plan.levels && (int)blockIdx.x >= plan.blk_start[level + 1]) ++level;
-    const VofeLevel L = lv[level];
-    const int b = (int)blockIdx.x - plan.blk_start[level];
-    const int bx = b % plan.blk_x[level], by = b / plan.blk_x[level];
+__device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int bx, int by, int img) {
     const int x0 = (bx * 64 + (threadIdx.x & 63)) * 8;
     const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= L.w || y >= L.h) return;
-    const long long so = (long long)(slot0 + (int)blockIdx.y) * L.slot_stride;
+    const long long so = (long long)(slot0 + img) * L.slot_stride;
     const uint8_t* r1 = L.I + so + (long long)y * L.pitch + x0;
     const uint8_t* r0 = r1 - L.pitch;
     const uint8_t* r2 = r1 + L.pitch;
@@ -271,6 +310,47 @@ __global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __res
     }
 }
 
+__global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __restrict__ lv, ScharrPlan plan, int slot0) {
+    int level = 0;
+    while (level + 1 < plan.levels && (int)blockIdx.x >= plan.blk_start[level + 1]) ++level;
+    const VofeLevel L = lv[level];
+    const int b = (int)blockIdx.x - plan.blk_start[level];
+    scharr_body(L, slot0, b % plan.blk_x[level], b / plan.blk_x[level], (int)blockIdx.y);
+}
+
+// One step of the level pipeline.  The pyrDown that produces level k (with its border bands) depends on level k-1 alone, and
+// so does every Scharr block of the levels below k: they share a launch -- blocks [0, pd_blocks) are pyrDown items, the rest
+// Scharr blocks of up to three level segments.  The upper-level pyrDowns are launch-bound by themselves (9-15 us for 1-4 MB
+// of traffic); the host spreads the Scharr blocks of levels 0 .. top-1 over the pyrDown launches so that every launch of
+// the chain is bandwidth-bound, and only the top level's Scharr pass is left for a launch of its own.
+constexpr int STEP_SEGS = 8;
+struct StepPlan {
+    int nseg;
+    int level[STEP_SEGS], blk_x[STEP_SEGS], first[STEP_SEGS];   // Scharr segment: level, blocks per row of blocks, first block (row-major)
+    int start[STEP_SEGS + 1];                                   // cumulative Scharr block counts of the segments (start[0] = 0)
+};
+// The grid is one-dimensional: the pyrDown blocks of ALL images first, then the Scharr blocks image by image.  (With the
+// images on grid.y the pyrDown blocks of the last images were dispatched at the end of the launch, and a pyrDown block's
+// fourteen-load latency chain then ran after the bandwidth-bound part was over: the launch took the sum, not the maximum.)
+__global__ __launch_bounds__(256) void pyr_step(const VofeLevel* __restrict__ lv, VofeLevel S, VofeLevel Dl, int slot0, int gpr, int items,
+                                                int win_w, int win_h, int pd_blocks, int count, StepPlan plan) {
+    // (the pyrDown's two level descriptors are kernel arguments: read out of the table in memory they cost the combined kernel
+    // 132 instead of 80 VGPRs, i.e. 3 instead of 6 wavefronts per SIMD for its Scharr blocks too)
+    const int npd = pd_blocks * count;
+    if ((int)blockIdx.x < npd) {
+        const int img = (int)blockIdx.x / pd_blocks, pb = (int)blockIdx.x - img * pd_blocks;
+        pyr_down_body<true>(S, Dl, slot0, gpr, items, win_w, win_h, pb * 256 + (int)threadIdx.x, img);
+    } else {
+        const int nsch = plan.start[plan.nseg];
+        const int q = (int)blockIdx.x - npd;
+        const int img = q / nsch, b = q - img * nsch;
+        int seg = 0;
+        while (seg + 1 < plan.nseg && b >= plan.start[seg + 1]) ++seg;
+        const int i = b - plan.start[seg] + plan.first[seg];
+        const VofeLevel L = lv[plan.level[seg]];
+        scharr_body(L, slot0, i % plan.blk_x[seg], i / plan.blk_x[seg], img);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fused pyramid: ONE launch produces the interiors of up to FUSE_MAX_LEVELS levels and their Scharr
@@ -632,15 +712,61 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
                                img_stride, L, slot0, wh, gx0, ngx, (int)items);
         }
     }
+    // border bands of levels 1..: written by pyr_down_u8 itself when one reflection reaches them on every such level
+    // (VOFE_PYR_BORDERS=separate keeps the border launch: tests, A/B), else by one pyramid_borders launch behind the chain
+    bool own_bands = !ctx->knobs.pyr_borders_separate;
+    for (int l = 1; l < pyr->levels; ++l) own_bands = own_bands && pyr->lv[l].w >= ww + 1 && pyr->lv[l].h >= wh + 1;
+    // level pipeline (needs the bands in the pyrDown launches and a derivative plane; VOFE_PYR_STEP=0 keeps the plain sequence):
+    // launch k = pyrDown (k-1 -> k) + Scharr of level k-1, then the last level's Scharr alone
+    const bool stepped = own_bands && pyr->with_deriv && pyr->levels > 1 && pyr->levels <= STEP_SEGS && !ctx->knobs.pyr_step_off;
     for (int l = 1; l < pyr->levels; ++l) {
         const VofeLevel& S = pyr->lv[l - 1];
         const VofeLevel& D = pyr->lv[l];
         const int gpr = (D.w + 7) / 8;
         const int items = gpr * ((D.h + 1) / 2);
+        const int pd_blocks = (items + 255) / 256;
+        if (stepped) {
+            // Scharr blocks of levels 0 .. top-1 in level order, [c0, c1) of them in this launch: a geometric share (half of
+            // what is left goes into every launch, the finest levels being the bulk), never beyond the levels that exist yet
+            const int top = pyr->levels - 1;
+            long long nblk[VOFE_MAX_LEVELS], cum[VOFE_MAX_LEVELS + 1];
+            cum[0] = 0;
+            for (int q = 0; q < top; ++q) {
+                nblk[q] = (long long)((pyr->lv[q].w + 511) / 512) * ((pyr->lv[q].h + 3) / 4);
+                cum[q + 1] = cum[q] + nblk[q];
+            }
+            const double denom = 1.0 - 1.0 / (double)(1ll << top);
+            auto share = [&](int k) {                                   // blocks handed out after launch k
+                if (k >= top) return cum[top];
+                long long c = (long long)((double)cum[top] * (1.0 - 1.0 / (double)(1ll << k)) / denom);
+                return c < cum[k] ? c : cum[k];                         // launch k sees levels 0 .. k-1 only
+            };
+            const long long c0 = share(l - 1), c1 = share(l);
+            StepPlan plan;
+            plan.nseg = 0;
+            plan.start[0] = 0;
+            for (int q = 0; q < top; ++q) {
+                const long long a = c0 > cum[q] ? c0 : cum[q], b = c1 < cum[q + 1] ? c1 : cum[q + 1];
+                if (b <= a) continue;
+                const int sgi = plan.nseg++;
+                plan.level[sgi] = q; plan.blk_x[sgi] = (pyr->lv[q].w + 511) / 512; plan.first[sgi] = (int)(a - cum[q]);
+                plan.start[sgi + 1] = plan.start[sgi] + (int)(b - a);
+            }
+            for (int sgi = plan.nseg; sgi < STEP_SEGS; ++sgi) { plan.level[sgi] = 0; plan.blk_x[sgi] = 1; plan.first[sgi] = 0; plan.start[sgi + 1] = plan.start[plan.nseg]; }
+            const long long total = ((long long)pd_blocks + plan.start[plan.nseg]) * count;
+            if (total > 0x7fffffffll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+            VOFE_TIMED(ctx, "pyr_step", l);
+            hipLaunchKernelGGL(pyr_step, dim3((unsigned)total), dim3(256), 0, st, pyr->d_lv, S, D, slot0, gpr, items, ww, wh,
+                               pd_blocks, count, plan);
+            continue;
+        }
         VOFE_TIMED(ctx, "pyr_down_u8", l);
-        hipLaunchKernelGGL(pyr_down_u8, dim3((items + 255) / 256, count), dim3(256), 0, st, S, D, slot0, gpr, items);
+        if (own_bands)
+            hipLaunchKernelGGL(pyr_down_u8<true>, dim3(pd_blocks, count), dim3(256), 0, st, S, D, slot0, gpr, items, ww, wh);
+        else
+            hipLaunchKernelGGL(pyr_down_u8<false>, dim3(pd_blocks, count), dim3(256), 0, st, S, D, slot0, gpr, items, ww, wh);
     }
-    if (pyr->levels > 1) {
+    if (pyr->levels > 1 && !own_bands) {
         // border bands of levels 1.. (level 0 got its border from pad_copy_level0: no blocks for it)
         launch_borders(ctx, pyr, 1, slot0, count, st);
     }
@@ -648,13 +774,14 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         ScharrPlan plan;
         plan.levels = pyr->levels;
         int total = 0;
+        const int first = stepped ? pyr->levels - 1 : 0;           // the pipeline has done every level but the last
         for (int l = 0; l < pyr->levels; ++l) {
             plan.blk_start[l] = total;
             plan.blk_x[l] = (pyr->lv[l].w + 511) / 512;
-            total += plan.blk_x[l] * ((pyr->lv[l].h + 3) / 4);
+            if (l >= first) total += plan.blk_x[l] * ((pyr->lv[l].h + 3) / 4);
         }
         plan.blk_start[pyr->levels] = total;
-        VOFE_TIMED(ctx, "scharr_deriv_s16x2");
+        VOFE_TIMED(ctx, stepped ? "scharr_deriv_s16x2 last" : "scharr_deriv_s16x2");
         hipLaunchKernelGGL(scharr_deriv_s16x2, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0);
     }
     hipError_t e = hipGetLastError();

@@ -30,6 +30,7 @@ struct VofeKnobs {
     bool pad_copy_generic;    // VOFE_PAD_COPY=generic: the any-width copy / border kernels
     bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
     int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
+    bool pyr_step_off;        // VOFE_PYR_STEP=0: per-level path without the level pipeline (pyrDown + Scharr sharing launches)
     int pyr_borders_separate; // VOFE_PYR_BORDERS=separate: the fused pyramid build leaves the border bands to a second launch (tests, A/B)
     int nms_rows;             // VOFE_NMS_ROWS: rows per thread of the NMS kernel, 1 / 2 / 4 / 8 (0 = by launch size)
     bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
