@@ -55,17 +55,18 @@ N_FRAMES = 8
 # Every entry names the kernel source it was measured on by content hash: when that file has changed since, the counter
 # figures are not printed as a roofline fraction ("pmc_stale": true, VALU frac null) until the passes are re-run.
 LK_PMC = {
-    # (the kernel with two window rows per register; before it: 651.0e6 instructions, 22137155 / 8 cycles, profiles/r02_pmc_inst.txt)
-    (64, 2000): {"valu_instr": 590664631.0, "cycles": 20955989.7 / 8, "fetch_kb": 1730305.2, "write_kb": 6231.0,
-                 "kernel_source": ("lk.hip", "3cf88250f762b881"),
-                 "source": "profiles/r02_pmc_inst_v5.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r02_pmc_fetch_v5.txt, r02_pmc_write_v5.txt"},
+    # (lk_track_kernel_x2<2, false>: 127 VGPRs, 4 wavefronts per SIMD; round 2's 150-VGPR kernel: 590.7e6 instructions in
+    # 20955989.7 / 8 cycles = 0.220, profiles/r02_pmc_inst_v5.txt)
+    (64, 2000): {"valu_instr": 579912631.0, "cycles": 18953860.3 / 8, "fetch_kb": 1848286.6, "write_kb": 6511.0,
+                 "kernel_source": ("lk.hip", "a2122ffb33864e06"),
+                 "source": "profiles/r03_pmc_inst_v1.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v1.txt, r03_pmc_write_v1.txt"},
 }
 # corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
 # instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
 SCORE_PMC = {
-    128: {"valu_instr": 73401216.0, "cycles": 2860728.7 / 8, "mix_bound_cycles_per_instr": 3.6,
-          "kernel_source": ("corners.hip", "b06d9bc5bf1a777c"),
-          "source": "profiles/r02_pmc_wait.txt, r02_pmc_inst_v5.txt (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs); "
+    128: {"valu_instr": 72438656.0, "cycles": 2826367.3 / 8, "mix_bound_cycles_per_instr": 3.6,
+          "kernel_source": ("corners.hip", "436d99d1c8b10d36"),
+          "source": "profiles/r03_pmc_inst_v1.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs); "
                     "mix: profiles/r03_score_kernel_experiments.txt"},
 }
 
@@ -111,9 +112,26 @@ def streaming_algorithmic_bytes(name, h, w, win, max_level, frames):
     if name.startswith("pyr_down_u8 L"):
         k = int(name.split("L")[-1])
         return frames * (px[k - 1] + px[k])
-    if name.startswith("pyr_step L"):                   # level pipeline: pyrDown (k-1 -> k) + Scharr of level k-1 in one launch
+    if name.startswith("pyr_step L"):
+        # level pipeline (csrc/pyramid.hip, vofe_launch_pyramid): pyrDown (k-1 -> k) + the k-th geometric share of the Scharr
+        # blocks (64 x 8 pixels x 4 rows each) of levels 0 .. top-1, never beyond level k-1
         k = int(name.split("L")[-1])
-        return frames * (px[k - 1] + px[k] + 5 * px[k - 1])
+        top = len(lv) - 1
+        nblk = [((b + 511) // 512) * ((a + 3) // 4) for a, b in lv[:top]]
+        cum = [0]
+        for q in range(top):
+            cum.append(cum[-1] + nblk[q])
+        denom = 1.0 - 1.0 / (1 << top)
+
+        def share(j):
+            return cum[top] if j >= top else min(int(cum[top] * (1.0 - 1.0 / (1 << j)) / denom), cum[j])
+        c0, c1 = share(k - 1), share(k)
+        scharr = 0.0
+        for q in range(top):
+            a, b = max(c0, cum[q]), min(c1, cum[q + 1])
+            if b > a:
+                scharr += 5.0 * px[q] * (b - a) / nblk[q]
+        return int(frames * (px[k - 1] + px[k] + scharr))
     if name.startswith("scharr_deriv_s16x2 last"):       # the last level's Scharr pass alone
         return frames * 5 * px[-1]
     if name.startswith("scharr_deriv"):
@@ -518,9 +536,9 @@ def run_rank(args):
                          "mix_bound_note": "the kernel's instructions are mostly the half-rate class (v_dot2_i32_i16, "
                                            "v_mad_i32_i24, v_add3, DPP adds: 4.1-4.2 cycles each in isolation, "
                                            "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD; "
-                                           "the two-rows-per-register arithmetic took 9 % of the instructions out (5.09 k -> "
-                                           "4.61 k per keypoint) for 5 % of the cycles, which lowers this fraction while the "
-                                           "launch got faster",
+                                           "round 3: the search-region loads moved behind the minimum-eigenvalue test, 150 -> 127 VGPRs = 4 "
+                                           "instead of 3 wavefronts per SIMD: 0.220 -> 0.239 instr/cycle/SIMD, i.e. the launch now runs at "
+                                           "the bound its instruction mix sets",
                          "hbm": hbm})
         else:
             roof.update(hbm)

@@ -139,11 +139,14 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
               int block_size, int aperture, int harris, double k, float* d_corners_xy,
               int capacity, int* h_n_out);
 
-/* vofe_gftt for callers that cannot allocate (code under HIP graph capture set-up, tight serving loops, harnesses
- * that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same results as vofe_gftt, but the
+/* vofe_gftt for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, set-up code that
+ * runs around a HIP graph capture).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same results as vofe_gftt, but the
  * detector's workspace (score map, candidate maps, bucket histograms, keys: 27 bytes per pixel + 129 KiB) is a static
  * device array inside the library instead of a buffer grown with hipMalloc, and the call itself allocates and frees
- * nothing (the array's address and the small pinned count header are set up by vofe_create).
+ * nothing (the array's address, the launch attribute of its last stage and the small pinned count header are set up by
+ * vofe_create).  Like vofe_gftt it is SYNCHRONOUS (it waits on the context's stream for the corner count), so it cannot
+ * be called INSIDE a stream capture; and with kernel timing switched on (vofe_profile_begin) the timing aid creates HIP
+ * events per launch, which is outside this guarantee.
  * Limit: height * width <= VOFE_NOALLOC_MAX_PIXELS (covers the reference's 640x480, 1241x376 and 800x600 frames);
  * larger frames are rejected with VOFE_E_UNSUPPORTED.  The array (14.3 MB) is held by every GPU the library runs on
  * until the process ends, keeps the previous call's contents (the call clears what must start at zero) and is shared

@@ -69,6 +69,49 @@ def test_noalloc_detector_equals_vofe_gftt_on_consecutive_calls(fe):
     _same(fe, malaga, 0, 0.01, 10)
 
 
+def test_noalloc_detector_on_a_fresh_context_allocates_nothing():
+    """The contract itself: on a context that has never run vofe_gftt (so nothing has grown its hipMalloc'ed workspace or
+    its pinned buffer) vofe_gftt_noalloc alone handles long and short candidate lists, a mask, Harris and a second
+    pass -- and the device's free memory does not move across those calls.  The first vofe_gftt afterwards is what
+    allocates (the free memory drops then), which also shows that the measurement can see an allocation."""
+    import torch
+    from visual_odometry_amd.frontend import FrontEnd
+    fe3 = FrontEnd(0)
+    big = synthetic.sequence(376, 1241, seed=0, n_frames=1)[0]
+    malaga = synthetic.sequence(600, 800, seed=1, n_frames=1)[0]
+    mask = np.zeros_like(big)
+    mask[50:300, 200:900] = 255
+    d_big, d_mal, d_mask = torch.from_numpy(big).cuda(), torch.from_numpy(malaga).cuda(), torch.from_numpy(mask).cuda()
+    outs = [torch.empty((3000, 2), dtype=torch.float32, device="cuda") for _ in range(2)]      # caller-owned outputs, made up front
+    n = C.c_int(0)
+
+    def call(d_img, maxc, md, d_m=None, harris=0, out=outs[0]):
+        h, w = d_img.shape
+        rc = fe3.L.vofe_gftt_noalloc(fe3.ctx, d_img.data_ptr(), h, w, d_img.stride(0), maxc, 0.01, float(md),
+                                     d_m.data_ptr() if d_m is not None else None, 3, 3, harris, 0.04, out.data_ptr(), 3000, C.byref(n))
+        assert rc == 0, fe3.L.vofe_last_error()
+        return n.value
+    call(d_big, 100, 7)                                     # warm-up: module load, first launches
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    counts = [call(d_big, 2000, 7), call(d_mal, 3000, 10), call(d_big, 300, 8, d_mask), call(d_big, 300, 8, None, 1),
+              call(d_mal, 3000, 0.5), call(d_big, 50, 40)]  # whole list, long list, mask, Harris, no suppression, wide suppression
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "vofe_gftt_noalloc changed the device's free memory"
+    ref = oracle.goodFeaturesToTrack(big, 50, 0.01, 40, nthreads=8).reshape(-1, 2)
+    assert counts[-1] == ref.shape[0] and np.array_equal(outs[0][:counts[-1]].cpu().numpy(), ref)
+    assert counts[0] == oracle.goodFeaturesToTrack(big, 2000, 0.01, 7, nthreads=8).shape[0]
+    # the allocating entry point on the same context: now the workspace is grown
+    h, w = d_mal.shape
+    rc = fe3.L.vofe_gftt(fe3.ctx, d_mal.data_ptr(), h, w, d_mal.stride(0), 3000, 0.01, 10.0, None, 3, 3, 0, 0.04,
+                         outs[1].data_ptr(), 3000, C.byref(n))
+    assert rc == 0 and n.value == counts[1]
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free0
+    assert np.array_equal(outs[1][:n.value].cpu().numpy(), oracle.goodFeaturesToTrack(malaga, 3000, 0.01, 10, nthreads=8).reshape(-1, 2))
+    fe3.close()
+
+
 def test_noalloc_detector_rejects_frames_beyond_its_static_workspace(fe):
     import torch
     d_img = torch.zeros((725, 725), dtype=torch.uint8, device="cuda")    # 525 625 px > 512 * 1024

@@ -1068,6 +1068,7 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 constexpr int VOFE_MAX_DEVICES = 64;
 static void* g_scratch_ptr[VOFE_MAX_DEVICES];        // per device: where THAT device's copy of `scratch` lives
+static bool g_fin_lds_set[VOFE_MAX_DEVICES];         // per device: finish_small's dynamic-LDS attribute has been set
 
 namespace {
 
@@ -1102,6 +1103,14 @@ int vofe_gftt_setup(vofe_ctx* ctx) {
         hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !ptr) return vofe_hip_fail(e, "hipGetSymbolAddress(scratch)");
         g_scratch_ptr[ctx->device] = ptr;
+    }
+    // finish_small launches with 120 KiB of dynamic LDS: the attribute that allows it belongs to the (current) device's copy
+    // of the kernel, so it is set here, once per device, not behind a process-wide flag at the first detector call
+    if (!g_fin_lds_set[ctx->device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(finish_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)FIN_MAX * (8 + 2)));
+        if (e != hipSuccess) return vofe_hip_fail(e, "hipFuncSetAttribute(finish_small, MaxDynamicSharedMemorySize): the one-block last stage needs 120 KiB of LDS");
+        g_fin_lds_set[ctx->device] = true;
     }
     // the pinned, device-mapped header every detector call reads its counts from: one image's worth now, so that the
     // no-allocation entry point finds it in place (batched calls and host corner lists grow it on demand)
@@ -1320,12 +1329,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         const bool fin = merged && use_rank && max_out > 0 && ub_fin + ub_fin / 4 <= FIN_MAX;
         bool split = !fin;
         if (fin) {
-            static bool lds_set = false;
-            const size_t fin_lds = (size_t)FIN_MAX * (8 + 2);
-            if (!lds_set) {
-                VOFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(finish_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-                lds_set = true;
-            }
+            const size_t fin_lds = (size_t)FIN_MAX * (8 + 2);                    // (its launch attribute: vofe_gftt_setup, once per device)
             { VOFE_TIMED(ctx, "finish_small");
             hipLaunchKernelGGL(finish_small, dim3(batch), dim3(1024), fin_lds, st, h, w, hdr, cand, lkey, lflag, suppress ? 0 : 1, seg,
                                d_corners_xy, capacity, max_out, reinterpret_cast<GfttHdr*>(ctx->d_pinned),

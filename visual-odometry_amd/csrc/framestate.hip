@@ -242,12 +242,17 @@ int vofe_framestate_reset(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
     return VOFE_OK;
 }
 
-int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, const float** h_tracked_xy,
-                          const uint8_t** h_status, int* n_landmarks, int* n_features, int* n_candidates_kept) {
-    if (!fs || !h_img || !h_tracked_xy || !h_status || !n_landmarks) { vofe_set_error("vofe_framestate_track: NULL argument"); return VOFE_E_ARG; }
-    if (fs->frame_index < 0) { vofe_set_error("vofe_framestate_track before vofe_framestate_reset"); return VOFE_E_ARG; }
-    if (fs->phase == 1) { vofe_set_error("vofe_framestate_track called twice without vofe_framestate_update"); return VOFE_E_ARG; }
-    if (pitch < fs->p.width) { vofe_set_error("vofe_framestate_track: pitch %d < width %d", pitch, fs->p.width); return VOFE_E_ARG; }
+// A failure after the frame has been pushed (frame_index advanced, resident arrays possibly half updated) leaves nothing a
+// later call could safely continue from: the object then demands vofe_framestate_reset, like after an overflow.
+static void invalidate_state(vofe_framestate* fs) {
+    hipStreamSynchronize(fs->s_trk);
+    hipStreamSynchronize(fs->s_det);
+    fs->frame_index = -1;
+    fs->phase = 0;
+}
+
+static int track_impl(vofe_framestate* fs, const uint8_t* h_img, int pitch, const float** h_tracked_xy,
+                      const uint8_t** h_status, int* n_landmarks, int* n_features, int* n_candidates_kept, bool* pushed) {
     int rc = bind(fs);
     if (rc) return rc;
     const vofe_framestate_params& p = fs->p;
@@ -256,6 +261,7 @@ int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
     // host copy made) BEFORE the wait for an update that vofe_framestate_update_async left running
     rc = push_frame(fs, h_img, pitch);
     if (rc) return rc;
+    *pushed = true;
     rc = collect_update(fs);
     if (rc) return rc;
     const int slot = fs->frame_index & 1;
@@ -296,10 +302,19 @@ int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, 
     return VOFE_OK;
 }
 
-int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep) {
-    if (!fs || !h_pose) { vofe_set_error("vofe_framestate_update: NULL argument"); return VOFE_E_ARG; }
-    if (fs->phase != 1) { vofe_set_error("vofe_framestate_update before vofe_framestate_track"); return VOFE_E_ARG; }
-    if (fs->K > 0 && !h_keep) { vofe_set_error("vofe_framestate_update: keep mask is NULL"); return VOFE_E_ARG; }
+int vofe_framestate_track(vofe_framestate* fs, const uint8_t* h_img, int pitch, const float** h_tracked_xy,
+                          const uint8_t** h_status, int* n_landmarks, int* n_features, int* n_candidates_kept) {
+    if (!fs || !h_img || !h_tracked_xy || !h_status || !n_landmarks) { vofe_set_error("vofe_framestate_track: NULL argument"); return VOFE_E_ARG; }
+    if (fs->frame_index < 0) { vofe_set_error("vofe_framestate_track before vofe_framestate_reset"); return VOFE_E_ARG; }
+    if (fs->phase == 1) { vofe_set_error("vofe_framestate_track called twice without vofe_framestate_update"); return VOFE_E_ARG; }
+    if (pitch < fs->p.width) { vofe_set_error("vofe_framestate_track: pitch %d < width %d", pitch, fs->p.width); return VOFE_E_ARG; }
+    bool pushed = false;
+    const int rc = track_impl(fs, h_img, pitch, h_tracked_xy, h_status, n_landmarks, n_features, n_candidates_kept, &pushed);
+    if (rc && pushed) invalidate_state(fs);        // the previous frame's points no longer match the pyramid slots
+    return rc;
+}
+
+static int update_impl(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep, bool* touched) {
     int rc = bind(fs);
     if (rc) return rc;
     const vofe_framestate_params& p = fs->p;
@@ -312,6 +327,7 @@ int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, cons
         return VOFE_E_ARG;
     }
     // landmarks the pose estimation kept (continuous.py:90-101): image points into the upload, world points in place
+    *touched = true;                               // from here on a failure leaves `world` and the resident arrays out of step
     const float* trk = reinterpret_cast<const float*>(fs->h_res);
     float* P1 = reinterpret_cast<float*>(fs->h_par + 192);
     for (int i = 0, o = 0; i < K; ++i) {
@@ -346,6 +362,16 @@ int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, cons
     fs->K1 = K1;
     fs->phase = 2;
     return VOFE_OK;
+}
+
+int vofe_framestate_update_async(vofe_framestate* fs, const double* h_pose, const uint8_t* h_keep) {
+    if (!fs || !h_pose) { vofe_set_error("vofe_framestate_update: NULL argument"); return VOFE_E_ARG; }
+    if (fs->phase != 1) { vofe_set_error("vofe_framestate_update before vofe_framestate_track"); return VOFE_E_ARG; }
+    if (fs->K > 0 && !h_keep) { vofe_set_error("vofe_framestate_update: keep mask is NULL"); return VOFE_E_ARG; }
+    bool touched = false;
+    const int rc = update_impl(fs, h_pose, h_keep, &touched);
+    if (rc && touched) invalidate_state(fs);       // world points compacted, device arrays not: only a reset can continue
+    return rc;
 }
 
 int vofe_framestate_wait(vofe_framestate* fs, int* n_promoted) {

@@ -268,18 +268,21 @@ class FrontEnd:
             return None, None, None
         pyr = self.pyramid(2, pair.shape[1], pair.shape[2], winSize, maxLevel)
         pyr.build(pair, 0)
-        d_prev = torch.from_numpy(p).to(self.device)
-        buf, d_next, d_err, d_st = self._packed_outputs(n)
-        if flags & OPTFLOW_USE_INITIAL_FLOW:
-            q = self._points(nextPts)
-            if q.shape != p.shape:
-                raise error(-1, "nextPts must match prevPts with OPTFLOW_USE_INITIAL_FLOW")
-            d_next.copy_(torch.from_numpy(q))
-        _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, 1, d_next.data_ptr(),
-                                        d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
-                                        float(criteria[2]), int(flags), float(minEigThreshold)))
-        nxt, st, err = self._unpack_outputs(buf, n)
-        self._stage_busy = False                  # the blocking download above is behind the frame upload on the same stream
+        # torch's copies below must queue on the CONTEXT's stream (a FrontEnd may be bound to a side stream while torch's
+        # current stream is another): uploads before the launch, the download behind it
+        with torch.cuda.stream(self.stream):
+            d_prev = torch.from_numpy(p).to(self.device)
+            buf, d_next, d_err, d_st = self._packed_outputs(n)
+            if flags & OPTFLOW_USE_INITIAL_FLOW:
+                q = self._points(nextPts)
+                if q.shape != p.shape:
+                    raise error(-1, "nextPts must match prevPts with OPTFLOW_USE_INITIAL_FLOW")
+                d_next.copy_(torch.from_numpy(q))
+            _lib.check(self.L.vofe_lk_track(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, 1, d_next.data_ptr(),
+                                            d_st.data_ptr(), d_err.data_ptr(), n, int(criteria[0]), int(criteria[1]),
+                                            float(criteria[2]), int(flags), float(minEigThreshold)))
+            nxt, st, err = self._unpack_outputs(buf, n)
+        self.synchronize()                        # the staging buffer is free again only once this stream has drained
         return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
 
     def _frame_pair(self, img_a, img_b, msg):
@@ -468,103 +471,104 @@ class FrontEnd:
         downloads the new one.  Ci/Fi/Ti are the candidate arrays of the previous FrameState, Pi/Xi the landmarks that
         survived pose estimation, `pose` the current 3x4 or 4x4 pose.  Returns (Pi, Xi, Ci, Fi, Ti) with the reference's
         shapes and dtypes.  (DeviceFrameState keeps the same arrays resident across frames instead.)"""
-        L, dev = self.L, self.device
-        lk = dict(winSize=(21, 21), maxLevel=3, criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3, fb_thresh=1.0)
-        lk.update(lk_params or {})
-        c_in, f_in, t_in = np.asarray(Ci), np.asarray(Fi), np.asarray(Ti)
-        P_in, X_in = np.asarray(Pi), np.asarray(Xi)
-        pose = np.asarray(pose)
-        n_c = c_in.shape[1] if c_in.ndim == 2 and c_in.size else 0
-        n_l = P_in.shape[1] if P_in.ndim == 2 else 0
-        tdim = t_in.shape[0] if t_in.ndim == 2 else 12
-        if n_c and (f_in.shape != c_in.shape or t_in.ndim != 2 or t_in.shape[1] != n_c or not 12 <= tdim <= 16):
-            raise error(-1, "expected Ci (2,M), Fi (2,M), Ti (12..16,M)")
-        if f_in.dtype not in (np.float32, np.float64):
-            raise error(-1, "Fi must be float32 or float64")
-        f64 = int(f_in.dtype == np.float64)
-        fdt = torch.float64 if f64 else torch.float32
+        with torch.cuda.stream(self.stream):         # every torch copy below queues on the context's stream, like the kernels
+            L, dev = self.L, self.device
+            lk = dict(winSize=(21, 21), maxLevel=3, criteria=_DEFAULT_CRITERIA, minEigThreshold=1e-3, fb_thresh=1.0)
+            lk.update(lk_params or {})
+            c_in, f_in, t_in = np.asarray(Ci), np.asarray(Fi), np.asarray(Ti)
+            P_in, X_in = np.asarray(Pi), np.asarray(Xi)
+            pose = np.asarray(pose)
+            n_c = c_in.shape[1] if c_in.ndim == 2 and c_in.size else 0
+            n_l = P_in.shape[1] if P_in.ndim == 2 else 0
+            tdim = t_in.shape[0] if t_in.ndim == 2 else 12
+            if n_c and (f_in.shape != c_in.shape or t_in.ndim != 2 or t_in.shape[1] != n_c or not 12 <= tdim <= 16):
+                raise error(-1, "expected Ci (2,M), Fi (2,M), Ti (12..16,M)")
+            if f_in.dtype not in (np.float32, np.float64):
+                raise error(-1, "Fi must be float32 or float64")
+            f64 = int(f_in.dtype == np.float64)
+            fdt = torch.float64 if f64 else torch.float32
 
-        # ---- detection (continuous.py:380-386): corners stay on the device
-        pair = self._frame_pair(img_prev, img_current, "img_prev and img_current must have the same size")
-        img = pair[1]
-        h, w = img.shape
-        cap_f = int(max_corners) if max_corners > 0 else h * w
-        d_feat = torch.empty((max(cap_f, 1), 2), dtype=torch.float32, device=dev)
-        n_f = C.c_int(0)
-        _lib.check(L.vofe_gftt(self.ctx, img.data_ptr(), h, w, img.stride(0), int(max_corners), float(quality_level),
-                               float(min_distance), None, 3, 3, 0, 0.04, d_feat.data_ptr(), max(cap_f, 1), C.byref(n_f)))
-        n_f = n_f.value
-        if n_f == 0:
-            np.float32(None).reshape(-1, 2)          # what the reference line does with cv2's None: raises
-        # ---- candidate tracking + compaction + distance band (continuous.py:389-405, :446-448), in place
-        cap_c = n_c + n_f
-        d_c = torch.empty((max(cap_c, 1), 2), dtype=torch.float32, device=dev)
-        d_f = torch.empty((max(cap_c, 1), 2), dtype=fdt, device=dev)
-        d_t = torch.empty((max(cap_c, 1), tdim), dtype=torch.float64, device=dev)
-        d_tri = torch.zeros(max(n_c, 1), dtype=torch.uint8, device=dev)
-        m = 0
-        if n_c:
-            d_prev = torch.from_numpy(np.ascontiguousarray(c_in.T.reshape(-1, 2).astype(np.float32))).to(dev)
-            d_f[:n_c].copy_(torch.from_numpy(np.ascontiguousarray(f_in.T)))
-            d_t[:n_c].copy_(torch.from_numpy(np.ascontiguousarray(t_in.T, dtype=np.float64)))
-            d_st = torch.empty(n_c, dtype=torch.uint8, device=dev)
-            d_err = torch.empty(n_c, dtype=torch.float32, device=dev)
-            pyr = self.pyramid(2, h, w, lk["winSize"], lk["maxLevel"])
-            pyr.build(pair, 0)
-            cr = lk["criteria"]
-            _lib.check(L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, 1, d_c.data_ptr(), d_st.data_ptr(),
-                                       d_err.data_ptr(), n_c, int(cr[0]), int(cr[1]), float(cr[2]), float(lk["minEigThreshold"]),
-                                       float(lk["fb_thresh"])))
-            m = self.filter_candidates_device(d_c[:n_c], d_st, d_f[:n_c], d_t[:n_c], d_tri, threshold_candidates_min,
-                                              threshold_candidates_max, threshold_triangulation)
-        # ---- de-duplication of the detections against candidates and landmarks (continuous.py:408-416)
-        if n_f and m + n_l == 0:
-            raise ValueError("zero-size array to reduction operation minimum which has no identity")    # np.min(axis=1) there
-        d_P = torch.empty((max(n_l + m, 1), 2), dtype=torch.float32, device=dev)
-        if n_l:
-            d_P[:n_l].copy_(torch.from_numpy(np.ascontiguousarray(P_in.T.reshape(-1, 2).astype(np.float32))))
-        d_mask = torch.empty(max(n_f, 1), dtype=torch.uint8, device=dev)
-        _lib.check(L.vofe_new_feature_mask2(self.ctx, d_feat.data_ptr(), n_f, d_c.data_ptr(), m, d_P.data_ptr(), n_l,
-                                            float(threshold_new_keypoints), d_mask.data_ptr()))
-        # ---- triangulation of matured candidates (continuous.py:450-475)
-        d_pose = torch.from_numpy(np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4])).to(dev)
-        d_prom = torch.zeros(max(m, 1), dtype=torch.uint8, device=dev)
-        d_xyz = torch.empty((max(m, 1), 3), dtype=torch.float64, device=dev)
-        if m:
-            d_K = torch.from_numpy(np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))).to(dev)
-            _lib.check(L.vofe_triangulate_candidates(self.ctx, d_K.data_ptr(), d_pose.data_ptr(), d_c.data_ptr(), d_f.data_ptr(), f64,
-                                                     d_t.data_ptr(), tdim, d_tri.data_ptr(), m, float(np.deg2rad(threshold_alpha_deg)),
-                                                     d_prom.data_ptr(), d_xyz.data_ptr()))
-        # ---- promotion, removal, append (continuous.py:476-495)
-        d_next = torch.empty((max(n_l + m + cap_c, 1), 2), dtype=torch.float32, device=dev)
-        d_new_xy = torch.empty((max(m, 1), 2), dtype=torch.float32, device=dev)
-        d_new_xyz = torch.empty((max(m, 1), 3), dtype=torch.float64, device=dev)
-        d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
-        _lib.check(L.vofe_candidate_commit(self.ctx, d_c.data_ptr(), d_f.data_ptr(), f64, d_t.data_ptr(), tdim, m, max(cap_c, 1),
-                                           d_prom.data_ptr(), d_xyz.data_ptr(), d_feat.data_ptr(), d_mask.data_ptr(), n_f,
-                                           d_pose.data_ptr(), d_P.data_ptr(), n_l, max(n_l + m, 1), d_next.data_ptr(),
-                                           d_new_xy.data_ptr(), d_new_xyz.data_ptr(), d_counts.data_ptr()))
-        n_prom, n_cand, _, overflow = (int(v) for v in d_counts.cpu().numpy())
-        if overflow:
-            raise error(-7, "handle_candidates: internal capacity exceeded")
-        flagged = bool(m) and bool(d_tri[:m].any().item())
-        self._stage_busy = False                        # the downloads above waited behind the frame upload on this stream
-        # ---- the new state, in the reference's layout and dtypes (numpy's hstack promotes where the reference appends)
-        c_base = np.float32 if n_c else np.float64       # track_keypoints hands back a float64 (2,0) array for no candidates
-        appended = n_cand > m - n_prom                   # continuous.py:487: new_features.size > 0
-        c_dt = np.result_type(c_base, np.float32) if appended else np.dtype(c_base)
-        f_dt = np.result_type(f_in.dtype, np.float32) if appended else f_in.dtype
-        t_dt = np.result_type(t_in.dtype, pose.dtype) if appended else t_in.dtype
-        Ci_o = d_c[:n_cand].cpu().numpy().T.astype(c_dt, copy=False)
-        Fi_o = d_f[:n_cand].cpu().numpy().T.astype(f_dt, copy=False)
-        Ti_o = d_t[:n_cand].cpu().numpy().T.astype(t_dt, copy=False)
-        if flagged:                                      # continuous.py:450: the landmark arrays are rebuilt whenever a candidate was flagged
-            new_xy = d_new_xy[:n_prom].cpu().numpy().T
-            Pi_o = np.concatenate([P_in, new_xy.astype(np.result_type(P_in.dtype, np.float32), copy=False)], axis=1)
-            Xi_o = np.concatenate([X_in, d_new_xyz[:n_prom].cpu().numpy().T], axis=1)
-        else:
-            Pi_o, Xi_o = Pi, Xi
-        return Pi_o, Xi_o, Ci_o, Fi_o, Ti_o
+            # ---- detection (continuous.py:380-386): corners stay on the device
+            pair = self._frame_pair(img_prev, img_current, "img_prev and img_current must have the same size")
+            img = pair[1]
+            h, w = img.shape
+            cap_f = int(max_corners) if max_corners > 0 else h * w
+            d_feat = torch.empty((max(cap_f, 1), 2), dtype=torch.float32, device=dev)
+            n_f = C.c_int(0)
+            _lib.check(L.vofe_gftt(self.ctx, img.data_ptr(), h, w, img.stride(0), int(max_corners), float(quality_level),
+                                   float(min_distance), None, 3, 3, 0, 0.04, d_feat.data_ptr(), max(cap_f, 1), C.byref(n_f)))
+            n_f = n_f.value
+            if n_f == 0:
+                np.float32(None).reshape(-1, 2)          # what the reference line does with cv2's None: raises
+            # ---- candidate tracking + compaction + distance band (continuous.py:389-405, :446-448), in place
+            cap_c = n_c + n_f
+            d_c = torch.empty((max(cap_c, 1), 2), dtype=torch.float32, device=dev)
+            d_f = torch.empty((max(cap_c, 1), 2), dtype=fdt, device=dev)
+            d_t = torch.empty((max(cap_c, 1), tdim), dtype=torch.float64, device=dev)
+            d_tri = torch.zeros(max(n_c, 1), dtype=torch.uint8, device=dev)
+            m = 0
+            if n_c:
+                d_prev = torch.from_numpy(np.ascontiguousarray(c_in.T.reshape(-1, 2).astype(np.float32))).to(dev)
+                d_f[:n_c].copy_(torch.from_numpy(np.ascontiguousarray(f_in.T)))
+                d_t[:n_c].copy_(torch.from_numpy(np.ascontiguousarray(t_in.T, dtype=np.float64)))
+                d_st = torch.empty(n_c, dtype=torch.uint8, device=dev)
+                d_err = torch.empty(n_c, dtype=torch.float32, device=dev)
+                pyr = self.pyramid(2, h, w, lk["winSize"], lk["maxLevel"])
+                pyr.build(pair, 0)
+                cr = lk["criteria"]
+                _lib.check(L.vofe_track_fb(self.ctx, pyr._h, 0, pyr._h, 1, d_prev.data_ptr(), None, 1, d_c.data_ptr(), d_st.data_ptr(),
+                                           d_err.data_ptr(), n_c, int(cr[0]), int(cr[1]), float(cr[2]), float(lk["minEigThreshold"]),
+                                           float(lk["fb_thresh"])))
+                m = self.filter_candidates_device(d_c[:n_c], d_st, d_f[:n_c], d_t[:n_c], d_tri, threshold_candidates_min,
+                                                  threshold_candidates_max, threshold_triangulation)
+            # ---- de-duplication of the detections against candidates and landmarks (continuous.py:408-416)
+            if n_f and m + n_l == 0:
+                raise ValueError("zero-size array to reduction operation minimum which has no identity")    # np.min(axis=1) there
+            d_P = torch.empty((max(n_l + m, 1), 2), dtype=torch.float32, device=dev)
+            if n_l:
+                d_P[:n_l].copy_(torch.from_numpy(np.ascontiguousarray(P_in.T.reshape(-1, 2).astype(np.float32))))
+            d_mask = torch.empty(max(n_f, 1), dtype=torch.uint8, device=dev)
+            _lib.check(L.vofe_new_feature_mask2(self.ctx, d_feat.data_ptr(), n_f, d_c.data_ptr(), m, d_P.data_ptr(), n_l,
+                                                float(threshold_new_keypoints), d_mask.data_ptr()))
+            # ---- triangulation of matured candidates (continuous.py:450-475)
+            d_pose = torch.from_numpy(np.ascontiguousarray(np.asarray(pose, dtype=np.float64)[:3, :4])).to(dev)
+            d_prom = torch.zeros(max(m, 1), dtype=torch.uint8, device=dev)
+            d_xyz = torch.empty((max(m, 1), 3), dtype=torch.float64, device=dev)
+            if m:
+                d_K = torch.from_numpy(np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))).to(dev)
+                _lib.check(L.vofe_triangulate_candidates(self.ctx, d_K.data_ptr(), d_pose.data_ptr(), d_c.data_ptr(), d_f.data_ptr(), f64,
+                                                         d_t.data_ptr(), tdim, d_tri.data_ptr(), m, float(np.deg2rad(threshold_alpha_deg)),
+                                                         d_prom.data_ptr(), d_xyz.data_ptr()))
+            # ---- promotion, removal, append (continuous.py:476-495)
+            d_next = torch.empty((max(n_l + m + cap_c, 1), 2), dtype=torch.float32, device=dev)
+            d_new_xy = torch.empty((max(m, 1), 2), dtype=torch.float32, device=dev)
+            d_new_xyz = torch.empty((max(m, 1), 3), dtype=torch.float64, device=dev)
+            d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+            _lib.check(L.vofe_candidate_commit(self.ctx, d_c.data_ptr(), d_f.data_ptr(), f64, d_t.data_ptr(), tdim, m, max(cap_c, 1),
+                                               d_prom.data_ptr(), d_xyz.data_ptr(), d_feat.data_ptr(), d_mask.data_ptr(), n_f,
+                                               d_pose.data_ptr(), d_P.data_ptr(), n_l, max(n_l + m, 1), d_next.data_ptr(),
+                                               d_new_xy.data_ptr(), d_new_xyz.data_ptr(), d_counts.data_ptr()))
+            n_prom, n_cand, _, overflow = (int(v) for v in d_counts.cpu().numpy())
+            if overflow:
+                raise error(-7, "handle_candidates: internal capacity exceeded")
+            flagged = bool(m) and bool(d_tri[:m].any().item())
+            self.synchronize()                               # staging buffer free again; everything queued on this stream has run
+            # ---- the new state, in the reference's layout and dtypes (numpy's hstack promotes where the reference appends)
+            c_base = np.float32 if n_c else np.float64       # track_keypoints hands back a float64 (2,0) array for no candidates
+            appended = n_cand > m - n_prom                   # continuous.py:487: new_features.size > 0
+            c_dt = np.result_type(c_base, np.float32) if appended else np.dtype(c_base)
+            f_dt = np.result_type(f_in.dtype, np.float32) if appended else f_in.dtype
+            t_dt = np.result_type(t_in.dtype, pose.dtype) if appended else t_in.dtype
+            Ci_o = d_c[:n_cand].cpu().numpy().T.astype(c_dt, copy=False)
+            Fi_o = d_f[:n_cand].cpu().numpy().T.astype(f_dt, copy=False)
+            Ti_o = d_t[:n_cand].cpu().numpy().T.astype(t_dt, copy=False)
+            if flagged:                                      # continuous.py:450: the landmark arrays are rebuilt whenever a candidate was flagged
+                new_xy = d_new_xy[:n_prom].cpu().numpy().T
+                Pi_o = np.concatenate([P_in, new_xy.astype(np.result_type(P_in.dtype, np.float32), copy=False)], axis=1)
+                Xi_o = np.concatenate([X_in, d_new_xyz[:n_prom].cpu().numpy().T], axis=1)
+            else:
+                Pi_o, Xi_o = Pi, Xi
+            return Pi_o, Xi_o, Ci_o, Fi_o, Ti_o
 
     def goodFeaturesToTrack_batch(self, images, maxCorners, qualityLevel, minDistance, useHarrisDetector=False,
                                   k=0.04):
