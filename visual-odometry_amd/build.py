@@ -11,9 +11,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fP
          "-Xclang", "-target-feature", "-Xclang", "-dot4-insts"]
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, extra_flags=(), out_name="libvofe.so"):
+    """extra_flags / out_name: A/B builds of a tuning macro (e.g. -DLK_X2_RS_PAD=8 -> libvofe_pad8.so, loaded through VOFE_LIB);
+    such a build passes the same no-scratch and hazard gates as the shipped library."""
     csrc = os.path.join(_HERE, "csrc")
-    out = os.path.join(_HERE, "libvofe.so")
+    out = os.path.join(_HERE, out_name)
     deps = [os.path.join(csrc, s) for s in SOURCES] + [os.path.join(csrc, "vofe_internal.h"),
                                                        os.path.join(_HERE, "..", "include", "vofe.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
@@ -23,7 +25,7 @@ def build_lib(force=False, verbose=False):
     # of the shipped kernels needs scratch, and the one experimental build that did (the two-keypoint tracker forced to 128
     # VGPRs) faulted the GPU (profiles/r02_overlap_experiments.txt).
     tmp = out                    # (compiled in place: the offload bundle embeds an id derived from the output name)
-    cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", tmp] + [os.path.join(csrc, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-Rpass-analysis=kernel-resource-usage", "-o", tmp] + [os.path.join(csrc, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -42,7 +44,7 @@ def build_lib(force=False, verbose=False):
     if not report:
         os.remove(tmp)
         raise RuntimeError("the compiler reported no kernel resources: cannot check for scratch use")
-    sites = sdwa_hazard_sites(hipcc, csrc)
+    sites = sdwa_hazard_sites(hipcc, csrc, extra_flags)
     if sites:
         os.remove(tmp)
         raise RuntimeError("lk.hip: a VALU instruction reads a register directly after the inline-assembly SDWA shift wrote "
@@ -50,7 +52,7 @@ def build_lib(force=False, verbose=False):
     return out
 
 
-def sdwa_hazard_sites(hipcc, csrc):
+def sdwa_hazard_sites(hipcc, csrc, extra_flags=()):
     """The one hazard the compiler cannot guard for us: lk.hip's inline-assembly SDWA shift writes half a register, and on
     the gfx940 family a directly following VALU reader of that register is not interlocked (LLVM adds the wait state only
     for SDWA instructions it selected itself).  The tracker source is compiled once more, device side only, to assembly,
@@ -63,7 +65,7 @@ def sdwa_hazard_sites(hipcc, csrc):
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "lk.s")
         flags = [f for f in FLAGS if f not in ("-fPIC", "-shared")]
-        subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", "-o", asm, os.path.join(csrc, "lk.hip")],
+        subprocess.run([hipcc] + flags + list(extra_flags) + ["--cuda-device-only", "-S", "-o", asm, os.path.join(csrc, "lk.hip")],
                        check=True, stderr=subprocess.DEVNULL)
         n, sites = audit.hazard_sites(open(asm).read())
     if n == 0:
