@@ -297,24 +297,32 @@ def run_rank(args):
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
+    ctrl = None                 # the process group that carries the barrier and the fold
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the ranks exchange nothing but the barrier and two 8-byte reductions of the timing: RCCL as the launch contract
-        # says, gloo if RCCL cannot come up on this node (recorded in the line as "rendezvous")
+        # The ranks exchange nothing but the barrier and two small reductions of the timing.  ONE rendezvous, on gloo (it comes up
+        # wherever a TCP store does: under torchrun the agent's store, under bench.py's own launcher rank 0's); RCCL, which the
+        # launch contract names, is a second group on the same store.  If RCCL cannot come up on this node (every rank agrees on
+        # that through the gloo group) the barrier stays on gloo and the line says so ("rendezvous").  No second rendezvous on
+        # another port: under torchrun nobody would host it and the ranks would wait for ever.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ok = 0.0
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            g = dist.new_group(backend="nccl")
             x = torch.zeros(1, device=torch.device("cuda", local_rank))
-            dist.all_reduce(x)
+            dist.all_reduce(x, group=g)
             torch.cuda.synchronize()
+            ok = 1.0
         except Exception as e:                                           # noqa: BLE001
-            print("bench.py rank %d: RCCL did not come up (%s); using gloo for the barrier" % (rank, str(e).splitlines()[0][:200]),
+            print("bench.py rank %d: RCCL did not come up (%s); the barrier stays on gloo" % (rank, str(e).splitlines()[0][:200]),
                   file=sys.stderr, flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    fold_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else None
+            g = None
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ctrl = g if flag.item() == 1.0 else None
+    on_rccl = ctrl is not None
+    fold_dev = None if (dist is None or on_rccl) else "cpu"
 
     from visual_odometry_amd import _lib
     from visual_odometry_amd.frontend import FrontEnd, Pyramid
@@ -426,7 +434,10 @@ def run_rank(args):
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            if on_rccl:
+                dist.barrier(group=ctrl, device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup * SETS):
@@ -469,7 +480,7 @@ def run_rank(args):
     rank_ok = 1.0
     if not args.no_cpu:
         rank_ok = 1.0 if verify_pairs(phases[0][2][:1], gpu_phase0, n)["ok"] else 0.0
-    elapsed, (tsum, frames_total, ok_ranks) = replicas.fold(dist, fold_dev or dev, elapsed, [tsum, frames_rank, rank_ok])
+    elapsed, (tsum, frames_total, ok_ranks) = replicas.fold(dist, fold_dev or dev, elapsed, [tsum, frames_rank, rank_ok], group=ctrl)
     fps = frames_total / elapsed
 
     out = None
@@ -552,7 +563,7 @@ def run_rank(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": scaling,
-            "rendezvous": (dist.get_backend() if dist is not None else "none"),
+            "rendezvous": ("none" if dist is None else ("nccl" if on_rccl else "gloo")),
             **({"rehearsal": "%d ranks share one GPU (--share-gpu): launcher / sharding / fold exercised, not a scaling figure" % world}
                if args.share_gpu else {}),
             "vs_baseline": None,
@@ -593,11 +604,11 @@ def run_rank(args):
         wk.pyr.free()
         wk.fe.close()
     fe.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if out is not None:
-        emit_result(out)
+        emit_result(out)                      # the line is out before the groups are torn down
+    if dist is not None:
+        dist.barrier()                        # (default group: gloo)
+        dist.destroy_process_group()
     return 0
 
 

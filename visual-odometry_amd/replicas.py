@@ -14,13 +14,14 @@ def shard(n_sequences, rank, world):
     return list(range(rank, n_sequences, world))
 
 
-def fold(dist, device, elapsed, units):
-    """(max over ranks of elapsed, sum over ranks of each entry of units).  dist may be None."""
+def fold(dist, device, elapsed, units, group=None):
+    """(max over ranks of elapsed, sum over ranks of each entry of units).  dist may be None; `group` is the process group
+    that carries the two reductions (None = the default group)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(elapsed), [float(u) for u in units]
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     u = torch.tensor(list(units), dtype=torch.float64, device=device)
-    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), [float(x) for x in u.tolist()]
