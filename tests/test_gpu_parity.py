@@ -1515,6 +1515,56 @@ def test_randomised_lk_21x21_sweep_all_kernels(fe, knob):
         knob("VOFE_LK")
 
 
+def test_randomised_pyramid_sweep_all_build_paths(fe, knob):
+    """Random frame sizes (ragged last groups of 8 and 16, levels that end early, levels barely larger than the window),
+    windows and level counts through every build path -- fused launch, per-level kernels as the level pipeline, as the plain
+    sequence with the pyrDown kernel's own border bands, and with the border launch -- on random, not band-limited content:
+    every level, its Scharr plane and its REFLECT_101 border, bit for bit, for a batch of three images."""
+    import os
+    import torch
+    from visual_odometry_amd.frontend import Pyramid
+    rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 31337)))
+    paths = (("fused", None, None), ("levels", None, None), ("levels", None, "0"), ("levels", "separate", None), ("fused", "separate", None))
+    for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40))):
+        win = (int(rng.integers(3, 42)), int(rng.integers(3, 42)))
+        h = int(rng.integers(win[1] + 1, 260))
+        w = int(rng.integers(max(win[0] + 1, 8), 420))
+        if case < 8:                                     # widths around the group sizes, with the reference's window
+            win = (21, 21)
+            w = (63, 64, 65, 71, 72, 73, 127, 129)[case]
+            h = (44, 45, 46, 47, 48, 49, 50, 51)[case]
+        lvl = int(rng.integers(0, 5))
+        imgs = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+        d = torch.from_numpy(imgs).cuda()
+        sizes = oracle.pyramid_sizes(h, w, win, lvl)
+        refs = [[oracle.pyramid_level(imgs[k], q) for q in range(len(sizes))] for k in range(3)]
+        mode, borders, step = paths[case % len(paths)]
+        knob("VOFE_PYRAMID", mode)
+        if borders:
+            knob("VOFE_PYR_BORDERS", borders)
+        else:
+            knob("VOFE_PYR_BORDERS")
+        if step:
+            knob("VOFE_PYR_STEP", step)
+        else:
+            knob("VOFE_PYR_STEP")
+        pyr = Pyramid(fe, 3, h, w, win, lvl, True)
+        pyr.build(d, 0)
+        assert pyr.levels == len(sizes), (case, h, w, win, lvl)
+        for k in range(3):
+            for q in range(pyr.levels):
+                got, der = pyr.download(k, q, deriv=True)
+                what = (case, mode, borders, step, h, w, win, lvl, k, q)
+                assert np.array_equal(got, refs[k][q]), what
+                assert np.array_equal(der, oracle.scharr(refs[k][q])), what
+                pad = pyr.download_padded(k, q)
+                assert np.array_equal(pad, np.pad(refs[k][q], ((win[1], win[1]), (win[0], win[0])), mode="reflect")), what
+        pyr.free()
+    knob("VOFE_PYRAMID")
+    knob("VOFE_PYR_BORDERS")
+    knob("VOFE_PYR_STEP")
+
+
 def test_randomised_gftt_sweep(fe):
     """40 random detector configurations (size, quality, minDistance incl. 0 and large, maxCorners, mask, Harris)."""
     import os
