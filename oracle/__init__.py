@@ -52,6 +52,7 @@ def lib():
         L.vofe_cpu_gftt.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p,
                                     C.c_int, C.c_double, f32p, C.c_int, i32p, C.c_int]
         L.vofe_cpu_set_variant.argtypes = [C.c_int] * 6
+        L.vofe_cpu_set_simd.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -69,6 +70,19 @@ SCORE_VARIANTS = {
     "all_fma": dict(sobel=1, mineig_fma=1, box_running=1, thresh_ipp=1),
 }
 HARRIS_VARIANTS = {"harris_scalar_f64": dict(harris=1), "harris_vector_f32": dict(harris=2)}
+
+
+class simd:
+    """with oracle.simd(): ...  -- the tracker's window loops vectorised (AVX2), bit-identical to the scalar restatement.  Used
+    by bench.py's cpu_baseline leg so that the CPU number beside the GPU's is not a scalar loop.  Process-wide."""
+
+    def __enter__(self):
+        lib().vofe_cpu_set_simd(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().vofe_cpu_set_simd(0)
+        return False
 
 
 class variant:

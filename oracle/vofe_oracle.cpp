@@ -20,6 +20,8 @@
  */
 #include "vofe_oracle.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -137,7 +139,7 @@ struct PlaneU8 {                                  // u8 level padded by (px,py),
     std::vector<uint8_t> buf;
     void alloc(int w_, int h_, int px_, int py_) {
         w = w_; h = h_; px = px_; py = py_; pitch = w + 2 * px;
-        buf.assign((size_t)pitch * (h + 2 * py), 0);
+        buf.assign((size_t)pitch * (h + 2 * py) + 64, 0);      // (+ slack: the vector loads of lk_point_simd read past a row's end)
     }
     uint8_t* row(int y) { return buf.data() + (size_t)(y + py) * pitch + px; }
     const uint8_t* row(int y) const { return buf.data() + (size_t)(y + py) * pitch + px; }
@@ -158,25 +160,32 @@ struct PlaneS16x2 {                               // (Ix,Iy) interleaved, zero p
     std::vector<int16_t> buf;
     void alloc(int w_, int h_, int px_, int py_) {
         w = w_; h = h_; px = px_; py = py_; pitch = 2 * (w + 2 * px);
-        buf.assign((size_t)pitch * (h + 2 * py), 0);
+        buf.assign((size_t)pitch * (h + 2 * py) + 64, 0);
     }
     int16_t* row(int y) { return buf.data() + (size_t)(y + py) * pitch + 2 * px; }
     const int16_t* row(int y) const { return buf.data() + (size_t)(y + py) * pitch + 2 * px; }
 };
 
-// SURVEY A.3 pyrDown 8U: 5x5 [1 4 6 4 1] separable, stride 2, (sum+128)>>8, REFLECT_101.
-void pyr_down(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch) {
-    int dw = (w + 1) / 2, dh = (h + 1) / 2;
+// SURVEY A.3 pyrDown 8U: 5x5 [1 4 6 4 1] separable, stride 2, (sum+128)>>8, REFLECT_101.  Output rows [Y0, Y1).
+void pyr_down_rows(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch, int Y0, int Y1) {
+    int dw = (w + 1) / 2;
     std::vector<int> rows((size_t)5 * dw);
-    for (int Y = 0; Y < dh; ++Y) {
+    const int Xa = std::min(dw, 1), Xb = std::max(Xa, (w - 3) / 2 + 1);      // X in [Xa, Xb): 2X-2 >= 0 and 2X+2 <= w-1, no reflection
+    for (int Y = Y0; Y < Y1; ++Y) {
         for (int k = 0; k < 5; ++k) {
             const uint8_t* s = src + (size_t)reflect101(2 * Y - 2 + k, h) * spitch;
             int* r = rows.data() + (size_t)k * dw;
-            for (int X = 0; X < dw; ++X) {
+            auto edge = [&](int X) {
                 int x0 = reflect101(2 * X - 2, w), x1 = reflect101(2 * X - 1, w), x2 = 2 * X,
                     x3 = reflect101(2 * X + 1, w), x4 = reflect101(2 * X + 2, w);
                 r[X] = s[x0] + 4 * s[x1] + 6 * s[x2] + 4 * s[x3] + s[x4];
+            };
+            for (int X = 0; X < Xa; ++X) edge(X);
+            for (int X = Xa; X < Xb; ++X) {
+                const uint8_t* q = s + 2 * X;
+                r[X] = q[-2] + 4 * q[-1] + 6 * q[0] + 4 * q[1] + q[2];
             }
+            for (int X = Xb; X < dw; ++X) edge(X);
         }
         const int *r0 = rows.data(), *r1 = r0 + dw, *r2 = r1 + dw, *r3 = r2 + dw, *r4 = r3 + dw;
         uint8_t* d = dst + (size_t)Y * dpitch;
@@ -184,16 +193,23 @@ void pyr_down(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dp
             d[X] = (uint8_t)((r0[X] + 4 * r1[X] + 6 * r2[X] + 4 * r3[X] + r4[X] + 128) >> 8);
     }
 }
+void pyr_down(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch, int nthreads = 1) {
+    parallel_for((h + 1) / 2, nthreads, [&](int Y0, int Y1) { pyr_down_rows(src, h, w, spitch, dst, dpitch, Y0, Y1); });
+}
 
 // SURVEY A.4 calcScharrDeriv: vertical pass t0 = 3(a+c)+10b, t1 = c-a; horizontal pass
-// Ix = t0[x+1]-t0[x-1], Iy = 3(t1[x-1]+t1[x+1])+10 t1[x]; REFLECT_101 both ways.
-void scharr(const uint8_t* src, int h, int w, int spitch, int16_t* dst, int dpitch) {
+// Ix = t0[x+1]-t0[x-1], Iy = 3(t1[x-1]+t1[x+1])+10 t1[x]; REFLECT_101 both ways.  Rows [y0, y1).
+void scharr_rows(const uint8_t* src, int h, int w, int spitch, int16_t* dst, int dpitch, int y0, int y1) {
     std::vector<int> t0(w + 2), t1(w + 2);
-    for (int y = 0; y < h; ++y) {
+    for (int y = y0; y < y1; ++y) {
         const uint8_t* a = src + (size_t)reflect101(y - 1, h) * spitch;
         const uint8_t* b = src + (size_t)y * spitch;
         const uint8_t* c = src + (size_t)reflect101(y + 1, h) * spitch;
-        for (int x = -1; x <= w; ++x) {
+        for (int x = 0; x < w; ++x) {
+            t0[x + 1] = 3 * (a[x] + c[x]) + 10 * b[x];
+            t1[x + 1] = c[x] - a[x];
+        }
+        for (int x : {-1, w}) {
             int sx = reflect101(x, w);
             t0[x + 1] = 3 * (a[sx] + c[sx]) + 10 * b[sx];
             t1[x + 1] = c[sx] - a[sx];
@@ -205,6 +221,9 @@ void scharr(const uint8_t* src, int h, int w, int spitch, int16_t* dst, int dpit
         }
     }
 }
+void scharr(const uint8_t* src, int h, int w, int spitch, int16_t* dst, int dpitch, int nthreads = 1) {
+    parallel_for(h, nthreads, [&](int y0, int y1) { scharr_rows(src, h, w, spitch, dst, dpitch, y0, y1); });
+}
 
 // SURVEY A.3 buildOpticalFlowPyramid
 struct Pyramid {
@@ -213,7 +232,7 @@ struct Pyramid {
     int max_level = 0;
 };
 void build_pyramid(Pyramid& P, const uint8_t* img, int h, int w, int pitch, int win_w, int win_h,
-                   int max_level, bool with_deriv) {
+                   int max_level, bool with_deriv, int nthreads = 1) {
     int lw = w, lh = h;
     for (int level = 0; level <= max_level; ++level) {
         P.I.emplace_back();
@@ -223,14 +242,14 @@ void build_pyramid(Pyramid& P, const uint8_t* img, int h, int w, int pitch, int 
             for (int y = 0; y < lh; ++y) memcpy(L.row(y), img + (size_t)y * pitch, lw);
         } else {
             const PlaneU8& S = P.I[level - 1];
-            pyr_down(S.row(0), S.h, S.w, S.pitch, L.row(0), L.pitch);
+            pyr_down(S.row(0), S.h, S.w, S.pitch, L.row(0), L.pitch, (size_t)lw * lh >= 32768 ? nthreads : 1);
         }
         L.fill_border();
         if (with_deriv) {
             P.D.emplace_back();
             PlaneS16x2& Dl = P.D.back();
             Dl.alloc(lw, lh, win_w, win_h);
-            scharr(L.row(0), lh, lw, L.pitch, Dl.row(0), Dl.pitch);
+            scharr(L.row(0), lh, lw, L.pitch, Dl.row(0), Dl.pitch, (size_t)lw * lh >= 32768 ? nthreads : 1);
         }
         P.max_level = level;
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
@@ -385,6 +404,162 @@ void lk_point(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float p
     nx = outx; ny = outy;
 }
 
+
+// ---------------------------------------------------------------- LK, AVX2 (the timed CPU baseline)
+// lk_point<false> eight window pixels at a time.  The same canonical arithmetic -- integer bilinear samples, exact integer
+// window sums converted to float once -- so the results are bit-identical to the scalar restatement (tests compare them); it
+// exists because the CPU baseline that bench.py reports beside the GPU number should not be a scalar loop when the reference's
+// cv2 runs SIMD code.  Layout trick as in OpenCV's own loop: pixel pairs (p[x], p[x+1]) as 16-bit halves of 32-bit lanes, one
+// _mm256_madd_epi16 against (w00, w01) / (w10, w11) per source row.
+bool g_simd = false;
+
+struct Acc64 {                                     // exact sum of 8 int32 lanes per call, kept in 4 int64 lanes
+    __m256i s = _mm256_setzero_si256();
+    inline void add(__m256i v32) {
+        s = _mm256_add_epi64(s, _mm256_cvtepi32_epi64(_mm256_castsi256_si128(v32)));
+        s = _mm256_add_epi64(s, _mm256_cvtepi32_epi64(_mm256_extracti128_si256(v32, 1)));
+    }
+    inline int64_t total() const {
+        alignas(32) int64_t t[4];
+        _mm256_store_si256((__m256i*)t, s);
+        return t[0] + t[1] + t[2] + t[3];
+    }
+};
+inline __m256i pairs_u8(const uint8_t* p) {        // lanes i = 0..7: p[i] | p[i+1] << 16
+    const __m128i a = _mm_loadl_epi64((const __m128i*)p), b = _mm_loadl_epi64((const __m128i*)(p + 1));
+    const __m128i lo = _mm_cvtepu8_epi16(a), hi = _mm_cvtepu8_epi16(b);
+    return _mm256_set_m128i(_mm_unpackhi_epi16(lo, hi), _mm_unpacklo_epi16(lo, hi));
+}
+inline __m256i lane_mask(int n) {                  // lanes < n all ones
+    alignas(32) static const int32_t idx[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    return _mm256_cmpgt_epi32(_mm256_set1_epi32(n), _mm256_load_si256((const __m256i*)idx));
+}
+
+void lk_point_simd(const Pyramid& prev, const Pyramid& next, const LKArgs& A, float px, float py,
+                   float& nx, float& ny, uint8_t& status, float& err, std::vector<int16_t>& buf) {
+    const int w = A.win_w, h = A.win_h;
+    const int wp = (w + 7) & ~7;                       // window row stride in the buffers (padded to whole vectors)
+    const float hx = (w - 1) * 0.5f, hy = (h - 1) * 0.5f;
+    const int maxLevel = prev.max_level;
+    buf.assign((size_t)3 * wp * h + 32, 0);
+    int16_t* Ip = buf.data();
+    int16_t* dIp = Ip + (size_t)wp * h;               // interleaved (ix, iy), 2 * wp per row
+    float outx = nx, outy = ny;
+    for (int level = maxLevel; level >= 0; --level) {
+        const PlaneU8& I = prev.I[level];
+        const PlaneS16x2& D = prev.D[level];
+        const PlaneU8& J = next.I[level];
+        const float sc = (float)(1. / (1 << level));
+        float ppx = px * sc, ppy = py * sc;
+        float npx, npy;
+        if (level == maxLevel) {
+            if (A.flags & 4) { npx = outx * sc; npy = outy * sc; }
+            else { npx = ppx; npy = ppy; }
+        } else { npx = outx * 2.f; npy = outy * 2.f; }
+        outx = npx; outy = npy;
+        ppx -= hx; ppy -= hy;
+        int ipx = floor_i(ppx), ipy = floor_i(ppy);
+        if (ipx < -w || ipx >= I.w || ipy < -h || ipy >= I.h) {
+            if (level == 0) { status = 0; err = 0.f; }
+            continue;
+        }
+        const Weights q = bilinear_weights(ppx, ppy, ipx, ipy);
+        const __m256i w0 = _mm256_set1_epi32((q.w00 & 0xffff) | (q.w01 << 16)), w1 = _mm256_set1_epi32((q.w10 & 0xffff) | (q.w11 << 16));
+        const __m256i r9 = _mm256_set1_epi32(1 << 8), r14 = _mm256_set1_epi32(1 << 13);
+        Acc64 a11, a12, a22;
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* s0 = I.row(ipy + y) + ipx;
+            const uint8_t* s1 = I.row(ipy + y + 1) + ipx;
+            const int16_t* d0 = D.row(ipy + y) + 2 * ipx;
+            const int16_t* d1 = D.row(ipy + y + 1) + 2 * ipx;
+            for (int x = 0; x < w; x += 8) {
+                const __m256i m = lane_mask(w - x);
+                __m256i iv = _mm256_add_epi32(_mm256_add_epi32(_mm256_madd_epi16(pairs_u8(s0 + x), w0), _mm256_madd_epi16(pairs_u8(s1 + x), w1)), r9);
+                iv = _mm256_srai_epi32(iv, 9);
+                // derivative pairs: lane i of A_ = (Ix_i, Iy_i), of B_ = (Ix_{i+1}, Iy_{i+1})
+                const __m256i A0 = _mm256_loadu_si256((const __m256i*)(d0 + 2 * x)), B0 = _mm256_loadu_si256((const __m256i*)(d0 + 2 * x + 2));
+                const __m256i A1 = _mm256_loadu_si256((const __m256i*)(d1 + 2 * x)), B1 = _mm256_loadu_si256((const __m256i*)(d1 + 2 * x + 2));
+                const __m256i X0 = _mm256_blend_epi16(A0, _mm256_slli_epi32(B0, 16), 0xAA), Y0 = _mm256_blend_epi16(_mm256_srli_epi32(A0, 16), B0, 0xAA);
+                const __m256i X1 = _mm256_blend_epi16(A1, _mm256_slli_epi32(B1, 16), 0xAA), Y1 = _mm256_blend_epi16(_mm256_srli_epi32(A1, 16), B1, 0xAA);
+                __m256i ix = _mm256_srai_epi32(_mm256_add_epi32(_mm256_add_epi32(_mm256_madd_epi16(X0, w0), _mm256_madd_epi16(X1, w1)), r14), 14);
+                __m256i iy = _mm256_srai_epi32(_mm256_add_epi32(_mm256_add_epi32(_mm256_madd_epi16(Y0, w0), _mm256_madd_epi16(Y1, w1)), r14), 14);
+                iv = _mm256_and_si256(iv, m); ix = _mm256_and_si256(ix, m); iy = _mm256_and_si256(iy, m);
+                // store: Ip as int16, dIp as (ix, iy) int16 pairs
+                const __m128i iv16 = _mm_packs_epi32(_mm256_castsi256_si128(iv), _mm256_extracti128_si256(iv, 1));
+                _mm_storeu_si128((__m128i*)(Ip + (size_t)y * wp + x), iv16);
+                const __m256i dd = _mm256_or_si256(_mm256_and_si256(ix, _mm256_set1_epi32(0xffff)), _mm256_slli_epi32(iy, 16));
+                _mm256_storeu_si256((__m256i*)(dIp + 2 * ((size_t)y * wp + x)), dd);
+                a11.add(_mm256_mullo_epi32(ix, ix)); a12.add(_mm256_mullo_epi32(ix, iy)); a22.add(_mm256_mullo_epi32(iy, iy));
+            }
+        }
+        float A11 = (float)a11.total() * FLT_SCALE, A12 = (float)a12.total() * FLT_SCALE, A22 = (float)a22.total() * FLT_SCALE;
+        float Dd = A11 * A22 - A12 * A12;
+        float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
+        if (A.flags & 8) err = minEig;
+        if (minEig < A.min_eig_thr || Dd < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        Dd = 1.f / Dd;
+        npx -= hx; npy -= hy;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < A.max_count; ++j) {
+            int inx = floor_i(npx), iny = floor_i(npy);
+            if (inx < -w || inx >= J.w || iny < -h || iny >= J.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            const Weights r = bilinear_weights(npx, npy, inx, iny);
+            const __m256i v0 = _mm256_set1_epi32((r.w00 & 0xffff) | (r.w01 << 16)), v1 = _mm256_set1_epi32((r.w10 & 0xffff) | (r.w11 << 16));
+            Acc64 b1a, b2a;
+            for (int y = 0; y < h; ++y) {
+                const uint8_t* j0 = J.row(iny + y) + inx;
+                const uint8_t* j1 = J.row(iny + y + 1) + inx;
+                __m256i r1 = _mm256_setzero_si256(), r2 = _mm256_setzero_si256();       // a row's partial sums fit int32
+                for (int x = 0; x < w; x += 8) {
+                    __m256i jv = _mm256_srai_epi32(_mm256_add_epi32(_mm256_add_epi32(_mm256_madd_epi16(pairs_u8(j0 + x), v0), _mm256_madd_epi16(pairs_u8(j1 + x), v1)), r9), 9);
+                    const __m256i ip = _mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i*)(Ip + (size_t)y * wp + x)));
+                    const __m256i diff = _mm256_sub_epi32(jv, ip);          // lanes past the window: garbage times (ix, iy) = (0, 0)
+                    const __m256i dd = _mm256_loadu_si256((const __m256i*)(dIp + 2 * ((size_t)y * wp + x)));
+                    r1 = _mm256_add_epi32(r1, _mm256_madd_epi16(_mm256_and_si256(diff, _mm256_set1_epi32(0xffff)), dd));
+                    r2 = _mm256_add_epi32(r2, _mm256_madd_epi16(_mm256_slli_epi32(diff, 16), dd));
+                }
+                b1a.add(r1); b2a.add(r2);
+            }
+            float b1 = (float)b1a.total() * FLT_SCALE, b2 = (float)b2a.total() * FLT_SCALE;
+            float dx = (A12 * b2 - A22 * b1) * Dd;
+            float dy = (A12 * b1 - A11 * b2) * Dd;
+            npx += dx; npy += dy;
+            outx = npx + hx; outy = npy + hy;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= A.eps2) break;
+            if (j > 0 && std::abs((double)(dx + pdx)) < 0.01 && std::abs((double)(dy + pdy)) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0 && !(A.flags & 8)) {
+            float ex = outx - hx, ey = outy - hy;
+            int inx = floor_i(ex), iny = floor_i(ey);
+            if (inx < -w || inx >= J.w || iny < -h || iny >= J.h) { status = 0; continue; }
+            const Weights r = bilinear_weights(ex, ey, inx, iny);
+            const __m256i v0 = _mm256_set1_epi32((r.w00 & 0xffff) | (r.w01 << 16)), v1 = _mm256_set1_epi32((r.w10 & 0xffff) | (r.w11 << 16));
+            Acc64 se;
+            for (int y = 0; y < h; ++y) {
+                const uint8_t* j0 = J.row(iny + y) + inx;
+                const uint8_t* j1 = J.row(iny + y + 1) + inx;
+                for (int x = 0; x < w; x += 8) {
+                    __m256i jv = _mm256_srai_epi32(_mm256_add_epi32(_mm256_add_epi32(_mm256_madd_epi16(pairs_u8(j0 + x), v0), _mm256_madd_epi16(pairs_u8(j1 + x), v1)), r9), 9);
+                    const __m256i ip = _mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i*)(Ip + (size_t)y * wp + x)));
+                    se.add(_mm256_and_si256(_mm256_abs_epi32(_mm256_sub_epi32(jv, ip)), lane_mask(w - x)));
+                }
+            }
+            err = (float)se.total() / (float)(32 * w * h);
+        }
+    }
+    nx = outx; ny = outy;
+}
+
 int lk_check(int h, int w, int n, int win_w, int win_h, int max_level) {
     if (h <= 0 || w <= 0 || n < 0) return -1;
     if (max_level < 0 || win_w <= 2 || win_h <= 2) return -2;
@@ -521,6 +696,8 @@ int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running,
     return 0;
 }
 
+int vofe_cpu_set_simd(int on) { g_simd = on != 0; return 0; }
+
 int vofe_cpu_pyr_down_u8(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch) {
     if (!src || !dst || h <= 0 || w <= 0) return -1;
     pyr_down(src, h, w, spitch, dst, dpitch);
@@ -570,15 +747,22 @@ int vofe_cpu_lk_track(const uint8_t* prev_img, const uint8_t* next_img, int h, i
     lk_criteria(crit_type, max_count, eps);
     A.max_count = max_count; A.eps2 = eps;
     Pyramid P, N;
-    build_pyramid(P, prev_img, h, w, pitch, win_w, win_h, max_level, true);
-    build_pyramid(N, next_img, h, w, pitch, win_w, win_h, max_level, false);
+    if (nthreads > 1) {                     // the two pyramids side by side, rows of the large levels over the threads
+        std::thread other([&] { build_pyramid(N, next_img, h, w, pitch, win_w, win_h, max_level, false, std::max(1, nthreads / 4)); });
+        build_pyramid(P, prev_img, h, w, pitch, win_w, win_h, max_level, true, std::max(1, nthreads - nthreads / 4));
+        other.join();
+    } else {
+        build_pyramid(P, prev_img, h, w, pitch, win_w, win_h, max_level, true);
+        build_pyramid(N, next_img, h, w, pitch, win_w, win_h, max_level, false);
+    }
     parallel_for(n, nthreads, [&](int lo, int hi) {
         std::vector<int16_t> buf;
         for (int i = lo; i < hi; ++i) {
             status[i] = 1;
             err[i] = 0.f;
             float nx = next_pts[2 * i], ny = next_pts[2 * i + 1];
-            if (g_variant.any_lk()) lk_point<true>(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
+            if (g_simd && !g_variant.any_lk()) lk_point_simd(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
+            else if (g_variant.any_lk()) lk_point<true>(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
             else lk_point<false>(P, N, A, prev_pts[2 * i], prev_pts[2 * i + 1], nx, ny, status[i], err[i], buf);
             next_pts[2 * i] = nx; next_pts[2 * i + 1] = ny;
         }

@@ -32,6 +32,10 @@ extern "C" {
  *   thresh_ipp  A.2 step 2: v < thr + FLT_EPSILON -> 0 */
 int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running, int harris, int thresh_ipp);
 
+/* 1: the tracker's window loops run eight pixels at a time (AVX2); same canonical arithmetic, bit-identical results (checked by
+ * tests/test_oracle_cpu.py).  For the timed CPU baseline of bench.py; the scalar loops stay the checker's definition. */
+int vofe_cpu_set_simd(int on);
+
 /* one pyrDown step, u8 -> u8, dst is ((w+1)/2, (h+1)/2). */
 int vofe_cpu_pyr_down_u8(const uint8_t* src, int h, int w, int spitch, uint8_t* dst, int dpitch);
 

@@ -193,6 +193,26 @@ def test_oracle_thread_count_invariance():
     assert all(np.array_equal(x, y) for x, y in zip(r1, r8))
 
 
+@pytest.mark.parametrize("win,lvl,flags", [((5, 5), 2, 0), ((8, 8), 1, 0), ((11, 11), 2, 0), ((21, 21), 3, 0), ((9, 15), 1, 0),
+                                           ((31, 17), 3, 0), ((21, 21), 2, 8), ((21, 21), 2, 4), ((33, 33), 0, 0)])
+def test_vector_tracker_is_bit_identical_to_the_scalar_restatement(win, lvl, flags):
+    """oracle.simd(): the window loops eight pixels at a time (AVX2), for bench.py's timed CPU baseline.  Same integer window
+    sums, so the outputs must equal the scalar loops' bit for bit -- ragged window widths, points hanging over every image
+    edge, min-eig errors, initial flow, and the multi-threaded pyramid build included."""
+    a, b = synthetic.sequence(120, 164, 9, 2)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 150, 0.01, 5), 260, 120, 164, 9)
+    edge = np.float32([[-3.5, 10], [0, 0], [163.2, 119.7], [170, 60], [80, -6.2], [81.5, 125.1], [1.25, 118.5], [162.5, 2.5], [400, 300], [-40, 50]])
+    pts = np.concatenate([pts.reshape(-1, 2), edge]).astype(np.float32)
+    init = (pts + np.float32([0.7, -0.4])).astype(np.float32) if flags & 4 else None
+    r0 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, win, lvl, (3, 30, 0.01), flags, 1e-4, nthreads=1)
+    with oracle.simd():
+        r1 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, win, lvl, (3, 30, 0.01), flags, 1e-4, nthreads=1)
+        r8 = oracle.calcOpticalFlowPyrLK(a, b, pts, init, win, lvl, (3, 30, 0.01), flags, 1e-4, nthreads=8)
+    for x, y, z in zip(r0, r1, r8):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert r0[1].any() and not r0[1].all()
+
+
 # ------------------------------------------------------------------ golden fixtures
 def test_golden_fixtures():
     """Fixtures written by tests/golden/make_golden.py from the oracle (small inputs); they catch
@@ -208,6 +228,9 @@ def test_golden_fixtures():
     n, s, e = oracle.calcOpticalFlowPyrLK(a, b, z["pts"], None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
     assert np.array_equal(n, z["lk_next"]) and np.array_equal(s, z["lk_status"]) and np.array_equal(e, z["lk_err"])
     t, s, e = oracle.track_keypoints(z["pts"].T, a, b, (11, 11), 2)
+    assert np.array_equal(t, z["fb_next"]) and np.array_equal(s, z["fb_status"])
+    with oracle.simd():
+        t, s, e = oracle.track_keypoints(z["pts"].T, a, b, (11, 11), 2, nthreads=4)
     assert np.array_equal(t, z["fb_next"]) and np.array_equal(s, z["fb_status"])
 
 
