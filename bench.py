@@ -112,25 +112,32 @@ def streaming_algorithmic_bytes(name, h, w, win, max_level, frames):
     if name.startswith("pyr_down_u8 L"):
         k = int(name.split("L")[-1])
         return frames * (px[k - 1] + px[k])
-    if name.startswith("pyr_step L"):
-        # level pipeline (csrc/pyramid.hip, vofe_launch_pyramid): pyrDown (k-1 -> k) + the k-th geometric share of the Scharr
-        # blocks (64 x 8 pixels x 4 rows each) of levels 0 .. top-1, never beyond level k-1
+    if name.startswith("pyr_step L") or name.startswith("pyr_tail L"):
+        # level pipeline (csrc/pyramid.hip, vofe_launch_pyramid): launch k = pyrDown (k-1 -> k) + the k-th geometric share of the
+        # Scharr blocks (64 x 8 pixels x 4 rows each) that ride on the pipeline, never beyond level k-1; its tail (default for
+        # 3+ levels, VOFE_PYR_TAIL=0 turns it off) produces the last one or two levels and their derivative planes from level
+        # `base` through LDS -- level `base` read once, every plane above it written once -- and carries the rest of the riders
         k = int(name.split("L")[-1])
         top = len(lv) - 1
-        nblk = [((b + 511) // 512) * ((a + 3) // 4) for a, b in lv[:top]]
+        tail = len(lv) >= 3 and os.environ.get("VOFE_PYR_TAIL", "")[:1] != "0"
+        base = max(1, top - 2) if tail else top
+        riders = base + 1 if tail else top
+        nblk = [((b + 511) // 512) * ((a + 3) // 4) for a, b in lv[:riders]]
         cum = [0]
-        for q in range(top):
+        for q in range(riders):
             cum.append(cum[-1] + nblk[q])
-        denom = 1.0 - 1.0 / (1 << top)
+        denom = 1.0 - 1.0 / (1 << riders)
 
         def share(j):
-            return cum[top] if j >= top else min(int(cum[top] * (1.0 - 1.0 / (1 << j)) / denom), cum[j])
+            return cum[riders] if j >= riders else min(int(cum[riders] * (1.0 - 1.0 / (1 << j)) / denom), cum[j])
         c0, c1 = share(k - 1), share(k)
         scharr = 0.0
-        for q in range(top):
+        for q in range(riders):
             a, b = max(c0, cum[q]), min(c1, cum[q + 1])
             if b > a:
                 scharr += 5.0 * px[q] * (b - a) / nblk[q]
+        if name.startswith("pyr_tail"):
+            return int(frames * (px[base] + 5 * sum(px[base + 1:]) + scharr))
         return int(frames * (px[k - 1] + px[k] + scharr))
     if name.startswith("scharr_deriv_s16x2 last"):       # the last level's Scharr pass alone
         return frames * 5 * px[-1]

@@ -65,15 +65,17 @@ def test_hip_path_against_the_committed_golden_fixture(fe):
                                             (64, 64, (21, 21), 3), (480, 640, (11, 11), 3),
                                             (33, 250, (5, 7), 2), (600, 800, (41, 41), 0), (23, 49, (21, 21), 0),
                                             (200, 333, (31, 17), 2)])
-@pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic", "fused-separate", "levels-separate", "levels-unstepped"])
+@pytest.mark.parametrize("path", ["fused", "levels", "fused-generic", "levels-generic", "fused-separate", "levels-separate", "levels-unstepped",
+                                  "levels-untailed", "levels-tail8"])
 def test_pyramid_and_scharr_bit_exact(fe, knob, h, w, win, levels, path):
     """Both build paths (one fused launch for small frames, per-level kernels for large ones), each with the
     divergence-free copy / border kernels where the levels are wide enough and with the any-width ones forced; the fused
     launch with the border bands written by the owners of their source pixels (default where every level is large enough
     for one reflection) and with the bands left to the border kernel (VOFE_PYR_BORDERS=separate); likewise the per-level
     pyrDown kernel, which writes the bands of the level it produces unless told to leave them to the border launch; the
-    default per-level path is the level pipeline (launch k = pyrDown to level k + Scharr of level k-1), "unstepped" the plain
-    sequence of the same kernels."""
+    default per-level path is the level pipeline (launch k = pyrDown to level k + a share of the Scharr blocks below it, the
+    last two levels from LDS in the pipeline's tail launch), "untailed" the pipeline with a pyrDown launch for every level,
+    "tail8" the tail kernel with its smaller tile, "unstepped" the plain sequence of the per-level kernels."""
     import torch
     knob("VOFE_PYRAMID", path.split("-")[0])
     if path.endswith("generic"):
@@ -82,6 +84,10 @@ def test_pyramid_and_scharr_bit_exact(fe, knob, h, w, win, levels, path):
         knob("VOFE_PYR_BORDERS", "separate")
     if path.endswith("unstepped"):
         knob("VOFE_PYR_STEP", "0")                 # pyrDown launches with their own border bands, Scharr of every level afterwards
+    if path.endswith("untailed"):
+        knob("VOFE_PYR_TAIL", "0")
+    if path.endswith("tail8"):
+        knob("VOFE_PYR_TAIL_TH", "8")
     from visual_odometry_amd.frontend import Pyramid
     imgs = _seq(h, w, seed=h + w, n=2)
     pyr = Pyramid(fe, 2, h, w, win, levels, True)
@@ -1524,11 +1530,16 @@ def test_randomised_pyramid_sweep_all_build_paths(fe, knob):
     import torch
     from visual_odometry_amd.frontend import Pyramid
     rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 31337)))
-    paths = (("fused", None, None), ("levels", None, None), ("levels", None, "0"), ("levels", "separate", None), ("fused", "separate", None))
+    paths = ({"VOFE_PYRAMID": "fused"}, {"VOFE_PYRAMID": "levels"}, {"VOFE_PYRAMID": "levels", "VOFE_PYR_STEP": "0"},
+             {"VOFE_PYRAMID": "levels", "VOFE_PYR_BORDERS": "separate"}, {"VOFE_PYRAMID": "fused", "VOFE_PYR_BORDERS": "separate"},
+             {"VOFE_PYRAMID": "levels", "VOFE_PYR_TAIL": "0"}, {"VOFE_PYRAMID": "levels", "VOFE_PYR_TAIL_TH": "8"})
+    names = ("VOFE_PYRAMID", "VOFE_PYR_BORDERS", "VOFE_PYR_STEP", "VOFE_PYR_TAIL", "VOFE_PYR_TAIL_TH")
     for case in range(int(os.environ.get("VOFE_SWEEP_CASES", 40))):
         win = (int(rng.integers(3, 42)), int(rng.integers(3, 42)))
         h = int(rng.integers(win[1] + 1, 260))
         w = int(rng.integers(max(win[0] + 1, 8), 420))
+        if case % 5 == 4:                                # frames of several tail tiles (64 x 16 top-level pixels each)
+            h, w = int(rng.integers(200, 520)), int(rng.integers(400, 1100))
         if case < 8:                                     # widths around the group sizes, with the reference's window
             win = (21, 21)
             w = (63, 64, 65, 71, 72, 73, 127, 129)[case]
@@ -1538,31 +1549,26 @@ def test_randomised_pyramid_sweep_all_build_paths(fe, knob):
         d = torch.from_numpy(imgs).cuda()
         sizes = oracle.pyramid_sizes(h, w, win, lvl)
         refs = [[oracle.pyramid_level(imgs[k], q) for q in range(len(sizes))] for k in range(3)]
-        mode, borders, step = paths[case % len(paths)]
-        knob("VOFE_PYRAMID", mode)
-        if borders:
-            knob("VOFE_PYR_BORDERS", borders)
-        else:
-            knob("VOFE_PYR_BORDERS")
-        if step:
-            knob("VOFE_PYR_STEP", step)
-        else:
-            knob("VOFE_PYR_STEP")
+        path = paths[case % len(paths)]
+        for name in names:
+            if name in path:
+                knob(name, path[name])
+            else:
+                knob(name)
         pyr = Pyramid(fe, 3, h, w, win, lvl, True)
         pyr.build(d, 0)
         assert pyr.levels == len(sizes), (case, h, w, win, lvl)
         for k in range(3):
             for q in range(pyr.levels):
                 got, der = pyr.download(k, q, deriv=True)
-                what = (case, mode, borders, step, h, w, win, lvl, k, q)
+                what = (case, sorted(path.items()), h, w, win, lvl, k, q)
                 assert np.array_equal(got, refs[k][q]), what
                 assert np.array_equal(der, oracle.scharr(refs[k][q])), what
                 pad = pyr.download_padded(k, q)
                 assert np.array_equal(pad, np.pad(refs[k][q], ((win[1], win[1]), (win[0], win[0])), mode="reflect")), what
         pyr.free()
-    knob("VOFE_PYRAMID")
-    knob("VOFE_PYR_BORDERS")
-    knob("VOFE_PYR_STEP")
+    for name in names:
+        knob(name)
 
 
 def test_randomised_gftt_sweep(fe):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes over tools/pmc_workload.py, one counter set per run (gfx950: at most 8 SQ / 4 TCC / 2 GRBM
-# counters per pass; FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).  Output: gpurun_out/pmc_<tag>/ + a summary
+# counters per pass; FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).  PMC_WORKLOAD=<script> replaces the workload.  Output: gpurun_out/pmc_<tag>/ + a summary
 # gpurun_out/pmc_<tag>.txt per pass.  usage: tools/pmc_passes.sh <tag-prefix> [pass ...]   (passes: fetch write inst lds l2)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,7 +20,7 @@ for p in $passes; do
   out=$R/gpurun_out/pmc_${pre}_$p
   rm -rf "$out"
   echo "== pass $p: $ctr"
-  timeout -s KILL 240 rocprofv3 --pmc $ctr -d "$out" -o x --output-format csv -- python3 "$R/tools/pmc_workload.py" > "$out.log" 2>&1 || { echo "pass $p failed"; tail -5 "$out.log"; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $ctr -d "$out" -o x --output-format csv -- python3 "$R/${PMC_WORKLOAD:-tools/pmc_workload.py}" > "$out.log" 2>&1 || { echo "pass $p failed"; tail -5 "$out.log"; exit 1; }
   python3 "$R/tools/pmc_sum.py" "$out" > "$R/gpurun_out/pmc_${pre}_$p.txt" || exit 1
   rm -rf "$out"
 done

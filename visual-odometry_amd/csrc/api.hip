@@ -40,6 +40,9 @@ void vofe_read_knobs(VofeKnobs* k) {
     k->nms_rows = env_int("VOFE_NMS_ROWS", 0);
     k->pyr_borders_separate = env_is("VOFE_PYR_BORDERS", 's');
     k->pyr_step_off = env_is("VOFE_PYR_STEP", '0');
+    k->pyr_tail_off = env_is("VOFE_PYR_TAIL", '0');
+    k->pyr_tail_split = env_is("VOFE_PYR_TAIL", 's');
+    k->pyr_tail_th = env_int("VOFE_PYR_TAIL_TH", 0);
     k->gftt_bitonic = env_is("VOFE_GFTT_SORT", 'b');
     k->gftt_debug = getenv("VOFE_GFTT_DEBUG") != nullptr;
     if (const char* v = getenv("VOFE_GFTT_CHAIN")) k->gftt_chain = v[0] == 's' ? 's' : (v[0] == 'r' ? 'r' : 0);

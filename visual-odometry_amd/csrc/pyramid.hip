@@ -9,6 +9,7 @@
 // that OpenCV materialises with copyMakeBorder is written by the same kernel that produces the
 // interior, so pyrDown / Scharr / LK never need index arithmetic at image edges.
 #include <cstdlib>
+#include <cstring>
 
 #include "vofe_internal.h"
 
@@ -115,6 +116,108 @@ __device__ __forceinline__ void store8u(uint8_t* p, unsigned a, unsigned b) {
     *reinterpret_cast<__attribute__((address_space(1))) u32x2v_unaligned*>((__attribute__((address_space(1))) uint8_t*)p) = q;
 }
 
+// 5x5 kernel of two output rows x eight outputs from seven source row segments (24 bytes each, starting 2 bytes left of the
+// first output's first tap): acc[o][j] += sum_k w_k * (row term of output j in source row k), exact integers.
+__device__ __forceinline__ void pyr_down_acc(const U4 (&ra)[7], const U2 (&rb)[7], unsigned (&acc)[2][8]) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const U4 a = ra[k];
+        const U2 b = rb[k];
+        const unsigned wv[6] = {a.a, a.b, a.c, a.d, b.a, b.b};
+        unsigned win[10];                          // win[m] = bytes 2+2m .. 5+2m of the row segment
+#pragma unroll
+        for (int m = 0; m < 10; ++m)
+            win[m] = (m & 1) ? wv[(m + 1) / 2] : __builtin_amdgcn_alignbyte(wv[m / 2 + 1], wv[m / 2], 2);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int t = k - 2 * o;               // tap index of this source row in output row o
+            if (t < 0 || t > 4) continue;
+            const unsigned wk = (t == 0 || t == 4) ? 1u : (t == 2 ? 6u : 4u);
+            const unsigned W = wk * 0x04060401u, E = wk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[o][j] = __builtin_amdgcn_udot4(win[j], W, acc[o][j], false);
+                acc[o][j] = __builtin_amdgcn_udot4(win[j + 2], E, acc[o][j], false);
+            }
+        }
+    }
+}
+
+// Eight pixels X0 .. X0+7 (X0 a multiple of 8) of row y of a level -> its plane: the row itself and, with BANDS, every border
+// position that mirrors one of these pixels (see above); without BANDS the two border columns either side that the next
+// pyrDown reads.
+template <bool BANDS>
+__device__ __forceinline__ void pyr_store_row(uint8_t* plane, const VofeLevel& Dl, int X0, int y, const unsigned (&out)[8],
+                                              int win_w, int win_h) {
+    const int w = Dl.w, h = Dl.h;
+    const bool full = X0 + 8 <= w;
+    const bool edge = X0 == 0 || X0 + 8 > w - 3;
+    const bool src_l = BANDS && X0 <= win_w;                   // holds a column of 1..win_w
+    const bool src_r = BANDS && X0 + 7 >= w - 1 - win_w;       // holds a column of w-1-win_w..w-2
+    const unsigned qx = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    const unsigned qy = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+    // destination rows: y itself and, with BANDS, its mirror images above the first / below the last image row
+    const int ny = 1 + ((BANDS && y >= 1 && y <= win_h) ? 1 : 0) + ((BANDS && y <= h - 2 && y >= h - 1 - win_h) ? 1 : 0);
+    for (int c = 0; c < ny; ++c) {
+        int yd = y;
+        if (c > 0) yd = (c == 1 && y >= 1 && y <= win_h) ? -y : 2 * (h - 1) - y;
+        uint8_t* drow = plane + (long long)yd * Dl.pitch;
+        if (full) *reinterpret_cast<uint2*>(drow + X0) = make_uint2(qx, qy);
+        if (BANDS) {
+            if (full) {
+                const unsigned rx = __builtin_bswap32(qy), rw = __builtin_bswap32(qx);      // the group byte-reversed
+                if (src_l) store8u(drow - X0 - 7, rx, rw);
+                if (src_r) store8u(drow + 2 * (w - 1) - X0 - 7, rx, rw);
+            } else if (X0 < w) {
+                // the ragged last group of a row (one thread per row): byte by byte
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int x = X0 + j;
+                    if (x < w) {
+                        drow[x] = (uint8_t)out[j];
+                        if (x >= 1 && x <= win_w) drow[-x] = (uint8_t)out[j];
+                        if (x <= w - 2 && x >= w - 1 - win_w) drow[2 * (w - 1) - x] = (uint8_t)out[j];
+                    }
+                }
+            }
+            continue;
+        }
+        if (edge) {
+            // Nearly every wavefront holds a thread at a row end (a 621-pixel row is 78 groups), so this path is as hot as
+            // the body: keep it to a handful of instructions.  Left end: columns 1 and 2 go to -1 and -2.  Right end:
+            // columns w-2 and w-3 go to w and w+1 (each is picked out of the owning group's eight outputs by a select
+            // chain).  A ragged last group stores its w - X0 valid bytes as 4 + 2 + 1.
+            if (X0 == 0) {
+                if (1 < w) drow[-1] = (uint8_t)out[1];
+                if (2 < w) drow[-2] = (uint8_t)out[2];
+            }
+            const int j2 = w - 2 - X0, j3 = w - 3 - X0;
+            unsigned v2 = out[0], v3 = out[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { v2 = j2 == j ? out[j] : v2; v3 = j3 == j ? out[j] : v3; }
+            if ((unsigned)j2 < 8u) drow[w] = (uint8_t)v2;
+            if ((unsigned)j3 < 8u) drow[w + 1] = (uint8_t)v3;
+            if (!full && X0 < w) {
+                const int nv = w - X0;                                                // 1..7
+                uint8_t* dp = drow + X0;
+                int o0 = 0;
+                if (nv & 4) { *reinterpret_cast<unsigned*>(dp) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o0 = 4; }
+                if (nv & 2) {
+                    const unsigned lo = o0 ? out[4] : out[0], hi = o0 ? out[5] : out[1];
+                    *reinterpret_cast<unsigned short*>(dp + o0) = (unsigned short)(lo | (hi << 8));
+                }
+                if (nv & 1) {
+                    const int jb = nv - 1;
+                    unsigned vb = out[0];
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) vb = jb == j ? out[j] : vb;
+                    dp[jb] = (uint8_t)vb;
+                }
+            }
+        }
+    }
+}
+
 template <bool BANDS>
 __device__ __forceinline__ void pyr_down_body(const VofeLevel& S, const VofeLevel& Dl, int slot0, int gpr, int items, int win_w, int win_h,
                                               int it, int img) {
@@ -138,103 +241,16 @@ __device__ __forceinline__ void pyr_down_body(const VofeLevel& S, const VofeLeve
         ra[k] = *reinterpret_cast<const U4*>(r);
         rb[k] = *reinterpret_cast<const U2*>(r + 16);
     }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const U4 a = ra[k];
-        const U2 b = rb[k];
-        const unsigned wv[6] = {a.a, a.b, a.c, a.d, b.a, b.b};
-        unsigned win[10];                          // win[m] = bytes 2+2m .. 5+2m of the row segment
-#pragma unroll
-        for (int m = 0; m < 10; ++m)
-            win[m] = (m & 1) ? wv[(m + 1) / 2] : __builtin_amdgcn_alignbyte(wv[m / 2 + 1], wv[m / 2], 2);
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int t = k - 2 * o;               // tap index of this source row in output row o
-            if (t < 0 || t > 4) continue;
-            const unsigned wk = (t == 0 || t == 4) ? 1u : (t == 2 ? 6u : 4u);
-            const unsigned W = wk * 0x04060401u, E = wk;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[o][j] = __builtin_amdgcn_udot4(win[j], W, acc[o][j], false);
-                acc[o][j] = __builtin_amdgcn_udot4(win[j + 2], E, acc[o][j], false);
-            }
-        }
-    }
-    const int w = Dl.w, h = Dl.h;
-    const bool full = X0 + 8 <= w;
-    const bool edge = X0 == 0 || X0 + 8 > w - 3;
-    const bool src_l = BANDS && X0 <= win_w;                   // holds a column of 1..win_w
-    const bool src_r = BANDS && X0 + 7 >= w - 1 - win_w;       // holds a column of w-1-win_w..w-2
+    pyr_down_acc(ra, rb, acc);
     uint8_t* plane = Dl.I + (long long)(slot0 + img) * Dl.slot_stride;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const int y = Y0 + o;
-        if (y >= h) break;
+        if (y >= Dl.h) break;
         unsigned out[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = acc[o][j] >> 8;
-        const unsigned qx = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-        const unsigned qy = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-        // destination rows: y itself and, with BANDS, its mirror images above the first / below the last image row
-        const int ny = 1 + ((BANDS && y >= 1 && y <= win_h) ? 1 : 0) + ((BANDS && y <= h - 2 && y >= h - 1 - win_h) ? 1 : 0);
-        for (int c = 0; c < ny; ++c) {
-            int yd = y;
-            if (c > 0) yd = (c == 1 && y >= 1 && y <= win_h) ? -y : 2 * (h - 1) - y;
-            uint8_t* drow = plane + (long long)yd * Dl.pitch;
-            if (full) *reinterpret_cast<uint2*>(drow + X0) = make_uint2(qx, qy);
-            if (BANDS) {
-                if (full) {
-                    const unsigned rx = __builtin_bswap32(qy), rw = __builtin_bswap32(qx);      // the group byte-reversed
-                    if (src_l) store8u(drow - X0 - 7, rx, rw);
-                    if (src_r) store8u(drow + 2 * (w - 1) - X0 - 7, rx, rw);
-                } else if (X0 < w) {
-                    // the ragged last group of a row (one thread per row): byte by byte
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int x = X0 + j;
-                        if (x < w) {
-                            drow[x] = (uint8_t)out[j];
-                            if (x >= 1 && x <= win_w) drow[-x] = (uint8_t)out[j];
-                            if (x <= w - 2 && x >= w - 1 - win_w) drow[2 * (w - 1) - x] = (uint8_t)out[j];
-                        }
-                    }
-                }
-                continue;
-            }
-            if (edge) {
-                // Nearly every wavefront holds a thread at a row end (a 621-pixel row is 78 groups), so this path is as hot as
-                // the body: keep it to a handful of instructions.  Left end: columns 1 and 2 go to -1 and -2.  Right end:
-                // columns w-2 and w-3 go to w and w+1 (each is picked out of the owning group's eight outputs by a select
-                // chain).  A ragged last group stores its w - X0 valid bytes as 4 + 2 + 1.
-                if (X0 == 0) {
-                    if (1 < w) drow[-1] = (uint8_t)out[1];
-                    if (2 < w) drow[-2] = (uint8_t)out[2];
-                }
-                const int j2 = w - 2 - X0, j3 = w - 3 - X0;
-                unsigned v2 = out[0], v3 = out[0];
-#pragma unroll
-                for (int j = 1; j < 8; ++j) { v2 = j2 == j ? out[j] : v2; v3 = j3 == j ? out[j] : v3; }
-                if ((unsigned)j2 < 8u) drow[w] = (uint8_t)v2;
-                if ((unsigned)j3 < 8u) drow[w + 1] = (uint8_t)v3;
-                if (!full && X0 < w) {
-                    const int nv = w - X0;                                                // 1..7
-                    uint8_t* dp = drow + X0;
-                    int o0 = 0;
-                    if (nv & 4) { *reinterpret_cast<unsigned*>(dp) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o0 = 4; }
-                    if (nv & 2) {
-                        const unsigned lo = o0 ? out[4] : out[0], hi = o0 ? out[5] : out[1];
-                        *reinterpret_cast<unsigned short*>(dp + o0) = (unsigned short)(lo | (hi << 8));
-                    }
-                    if (nv & 1) {
-                        const int jb = nv - 1;
-                        unsigned vb = out[0];
-#pragma unroll
-                        for (int j = 1; j < 7; ++j) vb = jb == j ? out[j] : vb;
-                        dp[jb] = (uint8_t)vb;
-                    }
-                }
-            }
-        }
+        pyr_store_row<BANDS>(plane, Dl, X0, y, out, win_w, win_h);
     }
 }
 
@@ -254,27 +270,15 @@ struct ScharrPlan {
     int levels;
 };
 
-__device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int bx, int by, int img) {
-    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 8;
-    const int y = by * 4 + (threadIdx.x >> 6);
-    if (x0 >= L.w || y >= L.h) return;
-    const long long so = (long long)(slot0 + img) * L.slot_stride;
-    const uint8_t* r1 = L.I + so + (long long)y * L.pitch + x0;
-    const uint8_t* r0 = r1 - L.pitch;
-    const uint8_t* r2 = r1 + L.pitch;
+// Eight derivative pixels x0 .. x0+7 of a row from the sixteen bytes x0-4 .. x0+11 of the rows above (a), at (bq) and below (c);
+// d = the row's derivative plane at x0, w = image width.
+__device__ __forceinline__ void scharr_emit(const unsigned (&a)[4], const unsigned (&bq)[4], const unsigned (&c)[4], int* d, int x0, int w) {
     int t0[10], t1[10];
-    {
-        unsigned a[4], bq[4], c[4];
-        U4 va = *reinterpret_cast<const U4*>(r0 - 4), vb = *reinterpret_cast<const U4*>(r1 - 4), vc = *reinterpret_cast<const U4*>(r2 - 4);
-        a[0] = va.a; a[1] = va.b; a[2] = va.c; a[3] = va.d;
-        bq[0] = vb.a; bq[1] = vb.b; bq[2] = vb.c; bq[3] = vb.d;
-        c[0] = vc.a; c[1] = vc.b; c[2] = vc.c; c[3] = vc.d;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int pa = (int)byte_of(a, i + 3), pb = (int)byte_of(bq, i + 3), pc = (int)byte_of(c, i + 3);
-            t0[i] = 3 * (pa + pc) + 10 * pb;
-            t1[i] = pc - pa;
-        }
+    for (int i = 0; i < 10; ++i) {
+        const int pa = (int)byte_of(a, i + 3), pb = (int)byte_of(bq, i + 3), pc = (int)byte_of(c, i + 3);
+        t0[i] = 3 * (pa + pc) + 10 * pb;
+        t1[i] = pc - pa;
     }
     unsigned o[8];
 #pragma unroll
@@ -283,9 +287,8 @@ __device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int b
         const int iy = 3 * (t1[i] + t1[i + 2]) + 10 * t1[i + 1];
         o[i] = ((unsigned)ix & 0xffffu) | ((unsigned)iy << 16);
     }
-    int* d = L.D + so + (long long)y * L.pitch + x0;
     // the last group of a row may run past w: those columns lie in the zero border, keep them 0
-    if (x0 + 8 <= L.w) {
+    if (x0 + 8 <= w) {
         // non-temporal: the derivative planes are written once and read back sparsely (windows around keypoints) by a
         // later launch; keeping them out of the caches' way is worth 1 % of the headline (48.99 k -> 49.51 k frames/s,
         // two runs each) because the tracker launch of the other stream lives on L2 / Infinity Cache hits
@@ -296,7 +299,7 @@ __device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int b
     } else {
         // ragged last group of a row: its w - x0 valid pixels as 4 + 2 + 1 (a third of the wavefronts of a 1241-pixel row
         // pass through here, so eight predicated single stores were ~10 % of the kernel's instructions)
-        const int nv = L.w - x0;                             // 1..7
+        const int nv = w - x0;                             // 1..7
         int o0 = 0;
         if (nv & 4) { *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]); o0 = 4; }
         if (nv & 2) { *reinterpret_cast<uint2*>(d + o0) = o0 ? make_uint2(o[4], o[5]) : make_uint2(o[0], o[1]); }
@@ -308,6 +311,22 @@ __device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int b
             d[jb] = (int)vb;
         }
     }
+}
+
+__device__ __forceinline__ void scharr_body(const VofeLevel& L, int slot0, int bx, int by, int img) {
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 8;
+    const int y = by * 4 + (threadIdx.x >> 6);
+    if (x0 >= L.w || y >= L.h) return;
+    const long long so = (long long)(slot0 + img) * L.slot_stride;
+    const uint8_t* r1 = L.I + so + (long long)y * L.pitch + x0;
+    const uint8_t* r0 = r1 - L.pitch;
+    const uint8_t* r2 = r1 + L.pitch;
+    unsigned a[4], bq[4], c[4];
+    U4 va = *reinterpret_cast<const U4*>(r0 - 4), vb = *reinterpret_cast<const U4*>(r1 - 4), vc = *reinterpret_cast<const U4*>(r2 - 4);
+    a[0] = va.a; a[1] = va.b; a[2] = va.c; a[3] = va.d;
+    bq[0] = vb.a; bq[1] = vb.b; bq[2] = vb.c; bq[3] = vb.d;
+    c[0] = vc.a; c[1] = vc.b; c[2] = vc.c; c[3] = vc.d;
+    scharr_emit(a, bq, c, L.D + so + (long long)y * L.pitch + x0, x0, L.w);
 }
 
 __global__ __launch_bounds__(256) void scharr_deriv_s16x2(const VofeLevel* __restrict__ lv, ScharrPlan plan, int slot0) {
@@ -352,6 +371,215 @@ __global__ __launch_bounds__(256) void pyr_step(const VofeLevel* __restrict__ lv
     }
 }
 
+__device__ __forceinline__ int refl1(int c, int n) {      // REFLECT_101 where one reflection is enough (small overshoot)
+    if (n == 1) return 0;
+    return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c);
+}
+
+// The tail of the level pipeline: the last one or two levels (their interiors, border bands and derivative planes) from
+// level `base` in ONE launch, together with the Scharr blocks that are still open.  The upper pyrDowns are 1-4 MB each: as
+// launches of their own they cost a dependent-launch latency each and run at 6-16 % of the memory rate.  Here a block owns a
+// tw x th tile of the top level and the matching twice larger tile of the level below it; it computes the regions those tiles
+// depend on (halo recompute, ~1.3x) from level `base` in global memory into LDS with the same v_dot4 row arithmetic as
+// pyr_down_body, the second level from the first out of LDS, and then writes its own tiles and their Scharr rows from LDS.
+// Region cells outside the image are never computed from the source's border (pyrDown of a REFLECT_101 extension is not the
+// REFLECT_101 extension of the pyrDown when the source width is even): they are filled by reflection inside the region, columns
+// first, then whole rows, before anything reads them.
+// Layout of a region row in LDS: cell i (level coordinate lox + i) at byte cell0 + i; cell0 of the lower region is 2, so that
+// the 24-byte segments the second pyrDown reads (from cell 16g - 2) are 16-byte aligned; the rows the output pass reads are
+// whole dwords around byte cell0 + (X0 - 4 - lox), shifted into place by v_alignbyte.
+struct TailPlan {
+    int D, base;                       // levels produced (1 or 2) from level `base`
+    int tw, th, halo;                  // top-level tile and the halo of its region
+    int tiles_x, tiles;                // tiles per row of tiles, tiles per image
+    int n[2], m[2], pitch[2], off[2], cell0[2];    // regions: [0] = level base+1, [D-1] = top level
+};
+constexpr int TAIL_LDS = 8192;
+
+// it / d for 0 <= it < 2^20 and small d, without the integer-division sequence (inv = 1.0f / d)
+__device__ __forceinline__ int div_small(int it, float inv) { return (int)(((float)it + 0.5f) * inv); }
+
+__device__ __forceinline__ void tail_fix_region(uint8_t* R, int n, int m, int pitch, int cell0, int lox, int loy, int w, int h) {
+    // (block-uniform: interior tiles have nothing to fill and skip both passes and their barriers)
+    if (lox >= 0 && loy >= 0 && lox + n <= w && loy + m <= h) return;
+    // columns of the in-image rows
+    const int nl = max(0, min(n, -lox)), r0 = max(0, w - lox), nr = max(0, n - r0), nc = nl + nr;
+    if (nc > 0) {
+        const float inv = 1.0f / (float)nc;
+        for (int it = (int)threadIdx.x; it < m * nc; it += 256) {
+            const int j = div_small(it, inv), c = it - j * nc;
+            const int i = c < nl ? c : r0 + (c - nl);
+            const int y = loy + j;
+            if (y < 0 || y >= h) continue;
+            const int si = vofe_reflect101(lox + i, w) - lox;
+            if (si < 0 || si >= n) continue;                       // (not a cell anything reads: its mirror would be in the region)
+            uint8_t* row = R + j * pitch + cell0;
+            row[i] = row[si];
+        }
+        __syncthreads();
+    }
+    // rows above and below the image, whole (columns included)
+    const int na = max(0, min(m, -loy)), b0 = max(0, h - loy), nb = max(0, m - b0), dwr = pitch >> 2;
+    if (na + nb > 0) {
+        const float inv = 1.0f / (float)dwr;
+        for (int it = (int)threadIdx.x; it < (na + nb) * dwr; it += 256) {
+            const int q = div_small(it, inv), e = it - q * dwr;
+            const int j = q < na ? q : b0 + (q - na);
+            const int sj = vofe_reflect101(loy + j, h) - loy;
+            if (sj < 0 || sj >= m) continue;
+            reinterpret_cast<unsigned*>(R + j * pitch)[e] = reinterpret_cast<const unsigned*>(R + sj * pitch)[e];
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void pyr_tail_tile(const VofeLevel& S, const VofeLevel& La, const VofeLevel& Lb, int slot, int win_w, int win_h,
+                                              const TailPlan& P, int tile, uint8_t* R) {
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int T = P.D - 1;
+    int lox[2], loy[2];
+    lox[T] = tx * P.tw - P.halo;
+    loy[T] = ty * P.th - P.halo;
+    if (T == 1) { lox[0] = 2 * lox[1] - 2; loy[0] = 2 * loy[1] - 2; }
+    // ---- region 0 from level `base` in global memory
+    {
+        const int gpr = (P.n[0] + 7) >> 3, prs = (P.m[0] + 1) >> 1;
+        const float inv = 1.0f / (float)gpr;
+        uint8_t* R0 = R + P.off[0];
+        const uint8_t* sbase = S.I + (long long)slot * S.slot_stride;
+        for (int it = (int)threadIdx.x; it < gpr * prs; it += 256) {
+            const int jp = div_small(it, inv), g = it - jp * gpr;
+            const int X0 = lox[0] + 8 * g, Y0 = loy[0] + 2 * jp;                    // both even
+            if (X0 >= La.w || X0 + 8 <= 0 || Y0 >= La.h || Y0 + 2 <= 0) continue;   // no pixel of it lies in the image
+            const uint8_t* sp = sbase + 2 * X0 - 4;
+            unsigned acc[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 128;
+            // source rows -2 .. S.h + 3 at most (0 <= Y0 < La.h): one reflection (S.h >= 2 La.h - 1 >= 7: La is taller than the window)
+            int ry[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) ry[k] = refl1(2 * Y0 - 2 + k, S.h);
+            U4 ra[7];
+            U2 rb[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const uint8_t* r = sp + (long long)ry[k] * S.pitch;
+                ra[k] = *reinterpret_cast<const U4*>(r);
+                rb[k] = *reinterpret_cast<const U2*>(r + 16);
+            }
+            pyr_down_acc(ra, rb, acc);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int j = 2 * jp + o;
+                if (j >= P.m[0]) break;
+                unsigned short* d = reinterpret_cast<unsigned short*>(R0 + j * P.pitch[0] + P.cell0[0] + 8 * g);     // cell0 is even
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q] = (unsigned short)((acc[o][2 * q] >> 8) | ((acc[o][2 * q + 1] >> 8) << 8));
+            }
+        }
+    }
+    __syncthreads();
+    tail_fix_region(R + P.off[0], P.n[0], P.m[0], P.pitch[0], P.cell0[0], lox[0], loy[0], La.w, La.h);
+    // ---- region 1 (the top level) from region 0
+    if (T == 1) {
+        const int gpr = (P.n[1] + 7) >> 3, prs = P.m[1] >> 1;                       // m[1] is even
+        const float inv = 1.0f / (float)gpr;
+        const uint8_t* R0 = R + P.off[0];
+        uint8_t* R1 = R + P.off[1];
+        for (int it = (int)threadIdx.x; it < gpr * prs; it += 256) {
+            const int jp = div_small(it, inv), g = it - jp * gpr;
+            const int X0 = lox[1] + 8 * g, Y0 = loy[1] + 2 * jp;
+            if (X0 >= Lb.w || X0 + 8 <= 0 || Y0 >= Lb.h || Y0 + 2 <= 0) continue;
+            unsigned acc[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 128;
+            U4 ra[7];
+            U2 rb[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const uint8_t* r = R0 + (4 * jp + k) * P.pitch[0] + 16 * g;         // cell 16g - 2 of region row 2 * (2 jp) + k
+                const uint4 v = *reinterpret_cast<const uint4*>(r);
+                const uint2 u = *reinterpret_cast<const uint2*>(r + 16);
+                ra[k].a = v.x; ra[k].b = v.y; ra[k].c = v.z; ra[k].d = v.w;
+                rb[k].a = u.x; rb[k].b = u.y;
+            }
+            pyr_down_acc(ra, rb, acc);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                uint8_t* d = R1 + (2 * jp + o) * P.pitch[1] + P.cell0[1] + 8 * g;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d[q] = (uint8_t)(acc[o][q] >> 8);
+            }
+        }
+        __syncthreads();
+        tail_fix_region(R + P.off[1], P.n[1], P.m[1], P.pitch[1], P.cell0[1], lox[1], loy[1], Lb.w, Lb.h);
+    }
+    // ---- own tiles of both levels: plane rows (+ border bands) and derivative rows, eight pixels per thread
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r > T) break;
+        const VofeLevel& L = r == 0 ? La : Lb;
+        const int d = T - r;
+        const int ox0 = (tx * P.tw) << d, oy0 = (ty * P.th) << d;
+        const int ox1 = min(ox0 + (P.tw << d), L.w), oy1 = min(oy0 + (P.th << d), L.h);
+        if (ox0 >= ox1 || oy0 >= oy1) continue;
+        const int gpr = (ox1 - ox0 + 7) >> 3, rows = oy1 - oy0;
+        const uint8_t* Rr = R + P.off[r];
+        const int pitch = P.pitch[r];
+        const long long so = (long long)slot * L.slot_stride;
+        uint8_t* plane = L.I + so;
+        const float inv = 1.0f / (float)gpr;
+        for (int it = (int)threadIdx.x; it < gpr * rows; it += 256) {
+            const int jr = div_small(it, inv), g = it - jr * gpr;
+            const int X0 = ox0 + 8 * g, y = oy0 + jr;
+            const int B = P.cell0[r] + (X0 - 4 - lox[r]);                           // byte of pixel X0 - 4 in a region row (>= 0)
+            const int ph = B & 3;
+            const uint8_t* r1 = Rr + (y - loy[r]) * pitch + (B - ph);
+            unsigned a[4], bq[4], c[4];
+            {
+                const unsigned* p0 = reinterpret_cast<const unsigned*>(r1 - pitch);
+                const unsigned* p1 = reinterpret_cast<const unsigned*>(r1);
+                const unsigned* p2 = reinterpret_cast<const unsigned*>(r1 + pitch);
+                unsigned la[4], lb[4], lc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { la[q] = p0[q]; lb[q] = p1[q]; lc[q] = p2[q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = __builtin_amdgcn_alignbyte(q < 3 ? la[q + 1] : 0u, la[q], ph);
+                    bq[q] = __builtin_amdgcn_alignbyte(q < 3 ? lb[q + 1] : 0u, lb[q], ph);
+                    c[q] = __builtin_amdgcn_alignbyte(q < 3 ? lc[q + 1] : 0u, lc[q], ph);
+                }
+            }
+            unsigned out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = byte_of(bq, 4 + j);
+            pyr_store_row<true>(plane, L, X0, y, out, win_w, win_h);
+            scharr_emit(a, bq, c, L.D + so + (long long)y * L.pitch + X0, X0, L.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pyr_tail(const VofeLevel* __restrict__ lv, VofeLevel S, VofeLevel La, VofeLevel Lb, int slot0,
+                                                int win_w, int win_h, TailPlan P, int count, StepPlan plan) {
+    __shared__ __attribute__((aligned(16))) uint8_t R[TAIL_LDS];
+    const int ntile = P.tiles * count;
+    // (tiles first: spreading them over the grid between the riders -- odd stride, so that they still land on all 8 XCDs --
+    // made the launch slower, 52 -> 54-65 us for 128 KITTI frames; profiles/r03_pyramid_chain.txt)
+    if ((int)blockIdx.x < ntile) {
+        const int img = (int)blockIdx.x / P.tiles, tile = (int)blockIdx.x - img * P.tiles;
+        pyr_tail_tile(S, La, Lb, slot0 + img, win_w, win_h, P, tile, R);
+    } else {
+        const int nsch = plan.start[plan.nseg];
+        const int q = (int)blockIdx.x - ntile;
+        const int img = q / nsch, b = q - img * nsch;
+        int seg = 0;
+        while (seg + 1 < plan.nseg && b >= plan.start[seg + 1]) ++seg;
+        const int i = b - plan.start[seg] + plan.first[seg];
+        const VofeLevel L = lv[plan.level[seg]];
+        scharr_body(L, slot0, i % plan.blk_x[seg], i / plan.blk_x[seg], img);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused pyramid: ONE launch produces the interiors of up to FUSE_MAX_LEVELS levels and their Scharr
 // planes.  A block owns a tw x th tile of the TOP level and the matching 2^d-times larger tiles of
@@ -366,10 +594,6 @@ struct FusePlan {
     int n[FUSE_MAX_LEVELS], m[FUSE_MAX_LEVELS], off[FUSE_MAX_LEVELS];
 };
 typedef unsigned u32_unaligned __attribute__((aligned(1)));
-__device__ __forceinline__ int refl1(int c, int n) {      // one reflection is enough here (|overshoot| <= 2)
-    if (n == 1) return 0;
-    return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c);
-}
 
 // band_w / band_h > 0: the block also writes the REFLECT_101 border bands (band_w columns left and right, band_h rows above
 // and below, corners included) whose SOURCE pixels it owns -- every border pixel mirrors exactly one interior pixel, so the
@@ -717,42 +941,48 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
     bool own_bands = !ctx->knobs.pyr_borders_separate;
     for (int l = 1; l < pyr->levels; ++l) own_bands = own_bands && pyr->lv[l].w >= ww + 1 && pyr->lv[l].h >= wh + 1;
     // level pipeline (needs the bands in the pyrDown launches and a derivative plane; VOFE_PYR_STEP=0 keeps the plain sequence):
-    // launch k = pyrDown (k-1 -> k) + Scharr of level k-1, then the last level's Scharr alone
+    // launch k = pyrDown (k-1 -> k) + a share of the Scharr blocks of the levels below k; the last one or two levels and what
+    // is left of the Scharr blocks in one pyr_tail launch (VOFE_PYR_TAIL=0: pyrDown launches up to the top level, then the
+    // top level's Scharr pass alone)
     const bool stepped = own_bands && pyr->with_deriv && pyr->levels > 1 && pyr->levels <= STEP_SEGS && !ctx->knobs.pyr_step_off;
-    for (int l = 1; l < pyr->levels; ++l) {
+    const int top = pyr->levels - 1;
+    const bool tail = stepped && pyr->levels >= 3 && !ctx->knobs.pyr_tail_off;
+    const int base = tail ? (top - 2 > 1 ? top - 2 : 1) : top;                 // levels above `base` are the tail's
+    // Scharr blocks of levels 0 .. riders-1 in level order ride on the pipeline's launches; launch k (1-based, the tail being
+    // the last) sees levels 0 .. k-1 and takes half of what is left (the finest levels are the bulk)
+    const int riders = tail ? base + 1 : top;
+    long long cum[VOFE_MAX_LEVELS + 1];
+    cum[0] = 0;
+    for (int q = 0; q < riders && stepped; ++q)
+        cum[q + 1] = cum[q] + (long long)((pyr->lv[q].w + 511) / 512) * ((pyr->lv[q].h + 3) / 4);
+    auto share = [&](int k) {                                       // blocks handed out after launch k
+        if (k >= riders) return cum[riders];
+        const double denom = 1.0 - 1.0 / (double)(1ll << riders);
+        long long c = (long long)((double)cum[riders] * (1.0 - 1.0 / (double)(1ll << k)) / denom);
+        return c < cum[k] ? c : cum[k];
+    };
+    auto rider_plan = [&](long long c0, long long c1) {
+        StepPlan plan;
+        plan.nseg = 0;
+        plan.start[0] = 0;
+        for (int q = 0; q < riders; ++q) {
+            const long long a = c0 > cum[q] ? c0 : cum[q], b = c1 < cum[q + 1] ? c1 : cum[q + 1];
+            if (b <= a) continue;
+            const int sgi = plan.nseg++;
+            plan.level[sgi] = q; plan.blk_x[sgi] = (pyr->lv[q].w + 511) / 512; plan.first[sgi] = (int)(a - cum[q]);
+            plan.start[sgi + 1] = plan.start[sgi] + (int)(b - a);
+        }
+        for (int sgi = plan.nseg; sgi < STEP_SEGS; ++sgi) { plan.level[sgi] = 0; plan.blk_x[sgi] = 1; plan.first[sgi] = 0; plan.start[sgi + 1] = plan.start[plan.nseg]; }
+        return plan;
+    };
+    for (int l = 1; l <= base; ++l) {
         const VofeLevel& S = pyr->lv[l - 1];
         const VofeLevel& D = pyr->lv[l];
         const int gpr = (D.w + 7) / 8;
         const int items = gpr * ((D.h + 1) / 2);
         const int pd_blocks = (items + 255) / 256;
         if (stepped) {
-            // Scharr blocks of levels 0 .. top-1 in level order, [c0, c1) of them in this launch: a geometric share (half of
-            // what is left goes into every launch, the finest levels being the bulk), never beyond the levels that exist yet
-            const int top = pyr->levels - 1;
-            long long nblk[VOFE_MAX_LEVELS], cum[VOFE_MAX_LEVELS + 1];
-            cum[0] = 0;
-            for (int q = 0; q < top; ++q) {
-                nblk[q] = (long long)((pyr->lv[q].w + 511) / 512) * ((pyr->lv[q].h + 3) / 4);
-                cum[q + 1] = cum[q] + nblk[q];
-            }
-            const double denom = 1.0 - 1.0 / (double)(1ll << top);
-            auto share = [&](int k) {                                   // blocks handed out after launch k
-                if (k >= top) return cum[top];
-                long long c = (long long)((double)cum[top] * (1.0 - 1.0 / (double)(1ll << k)) / denom);
-                return c < cum[k] ? c : cum[k];                         // launch k sees levels 0 .. k-1 only
-            };
-            const long long c0 = share(l - 1), c1 = share(l);
-            StepPlan plan;
-            plan.nseg = 0;
-            plan.start[0] = 0;
-            for (int q = 0; q < top; ++q) {
-                const long long a = c0 > cum[q] ? c0 : cum[q], b = c1 < cum[q + 1] ? c1 : cum[q + 1];
-                if (b <= a) continue;
-                const int sgi = plan.nseg++;
-                plan.level[sgi] = q; plan.blk_x[sgi] = (pyr->lv[q].w + 511) / 512; plan.first[sgi] = (int)(a - cum[q]);
-                plan.start[sgi + 1] = plan.start[sgi] + (int)(b - a);
-            }
-            for (int sgi = plan.nseg; sgi < STEP_SEGS; ++sgi) { plan.level[sgi] = 0; plan.blk_x[sgi] = 1; plan.first[sgi] = 0; plan.start[sgi + 1] = plan.start[plan.nseg]; }
+            const StepPlan plan = rider_plan(share(l - 1), share(l));
             const long long total = ((long long)pd_blocks + plan.start[plan.nseg]) * count;
             if (total > 0x7fffffffll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
             VOFE_TIMED(ctx, "pyr_step", l);
@@ -766,6 +996,48 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         else
             hipLaunchKernelGGL(pyr_down_u8<false>, dim3(pd_blocks, count), dim3(256), 0, st, S, D, slot0, gpr, items, ww, wh);
     }
+    if (tail) {
+        TailPlan P;
+        memset(&P, 0, sizeof(P));
+        P.D = top - base;                                           // 1 or 2
+        P.base = base;
+        const int T = P.D - 1;
+        if (P.D == 2) { P.tw = 64; P.th = ctx->knobs.pyr_tail_th == 8 ? 8 : 16; P.halo = 1; P.cell0[0] = 2; P.cell0[1] = 3; }
+        else { P.tw = 128; P.th = 32; P.halo = 2; P.cell0[0] = 2; }   // (halo 2: the region's origin must be even for the aligned source loads)
+        P.n[T] = P.tw + 2 * P.halo; P.m[T] = P.th + 2 * P.halo;
+        if (T == 1) { P.n[0] = 2 * P.n[1] + 3; P.m[0] = 2 * P.m[1] + 3; }
+        int off = 0;
+        for (int r = 0; r <= T; ++r) {
+            int pitch = P.cell0[r] + (P.n[r] + 7) / 8 * 8 + 16;
+            if (r == 0 && T == 1 && pitch < 16 * ((P.n[1] + 7) / 8) + 8) pitch = 16 * ((P.n[1] + 7) / 8) + 8;
+            P.pitch[r] = (pitch + 15) / 16 * 16;
+            P.off[r] = off;
+            off += P.pitch[r] * P.m[r];
+        }
+        if (off > TAIL_LDS) { vofe_set_error("pyramid: tail plan needs %d bytes of LDS", off); return VOFE_E_UNSUPPORTED; }
+        const VofeLevel& Lt = pyr->lv[top];
+        P.tiles_x = (Lt.w + P.tw - 1) / P.tw;
+        P.tiles = P.tiles_x * ((Lt.h + P.th - 1) / P.th);
+        const StepPlan plan = rider_plan(share(base), share(base + 1));
+        const long long total = ((long long)P.tiles + plan.start[plan.nseg]) * count;
+        if (total > 0x7fffffffll) { vofe_set_error("pyramid: image too large"); return VOFE_E_UNSUPPORTED; }
+        if (ctx->knobs.pyr_tail_split) {                            // measurement: tiles and riders as two launches
+            {
+                VOFE_TIMED(ctx, "pyr_tail tiles", base + 1);
+                hipLaunchKernelGGL(pyr_tail, dim3((unsigned)(P.tiles * count)), dim3(256), 0, st, pyr->d_lv, pyr->lv[base], pyr->lv[base + 1],
+                                   pyr->lv[top], slot0, ww, wh, P, count, rider_plan(0, 0));
+            }
+            TailPlan Q = P;
+            Q.tiles = 0;
+            VOFE_TIMED(ctx, "pyr_tail riders", base + 1);
+            hipLaunchKernelGGL(pyr_tail, dim3((unsigned)(plan.start[plan.nseg] * count)), dim3(256), 0, st, pyr->d_lv, pyr->lv[base], pyr->lv[base + 1],
+                               pyr->lv[top], slot0, ww, wh, Q, count, plan);
+        } else {
+            VOFE_TIMED(ctx, "pyr_tail", base + 1);
+            hipLaunchKernelGGL(pyr_tail, dim3((unsigned)total), dim3(256), 0, st, pyr->d_lv, pyr->lv[base], pyr->lv[base + 1],
+                               pyr->lv[top], slot0, ww, wh, P, count, plan);
+        }
+    }
     if (pyr->levels > 1 && !own_bands) {
         // border bands of levels 1.. (level 0 got its border from pad_copy_level0: no blocks for it)
         launch_borders(ctx, pyr, 1, slot0, count, st);
@@ -774,15 +1046,17 @@ int vofe_launch_pyramid(vofe_ctx* ctx, vofe_pyr* pyr, int slot0, int count, cons
         ScharrPlan plan;
         plan.levels = pyr->levels;
         int total = 0;
-        const int first = stepped ? pyr->levels - 1 : 0;           // the pipeline has done every level but the last
+        const int first = tail ? pyr->levels : (stepped ? pyr->levels - 1 : 0);     // the pipeline has done every level but the last, its tail that one too
         for (int l = 0; l < pyr->levels; ++l) {
             plan.blk_start[l] = total;
             plan.blk_x[l] = (pyr->lv[l].w + 511) / 512;
             if (l >= first) total += plan.blk_x[l] * ((pyr->lv[l].h + 3) / 4);
         }
         plan.blk_start[pyr->levels] = total;
-        VOFE_TIMED(ctx, stepped ? "scharr_deriv_s16x2 last" : "scharr_deriv_s16x2");
-        hipLaunchKernelGGL(scharr_deriv_s16x2, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0);
+        if (total > 0) {
+            VOFE_TIMED(ctx, stepped ? "scharr_deriv_s16x2 last" : "scharr_deriv_s16x2");
+            hipLaunchKernelGGL(scharr_deriv_s16x2, dim3(total, count), dim3(256), 0, st, pyr->d_lv, plan, slot0);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "pyramid launch");

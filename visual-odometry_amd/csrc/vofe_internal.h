@@ -31,6 +31,9 @@ struct VofeKnobs {
     bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
     int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
     bool pyr_step_off;        // VOFE_PYR_STEP=0: per-level path without the level pipeline (pyrDown + Scharr sharing launches)
+    bool pyr_tail_off;        // VOFE_PYR_TAIL=0: level pipeline without its tail kernel (every level a pyrDown launch, the top level's Scharr pass alone)
+    bool pyr_tail_split;      // VOFE_PYR_TAIL=split: the tail's tiles and its Scharr riders as two launches (measurement)
+    int pyr_tail_th;          // VOFE_PYR_TAIL_TH: rows of the tail kernel's top-level tile, 8 or 16 (0 = 16)
     int pyr_borders_separate; // VOFE_PYR_BORDERS=separate: the fused pyramid build leaves the border bands to a second launch (tests, A/B)
     int nms_rows;             // VOFE_NMS_ROWS: rows per thread of the NMS kernel, 1 / 2 / 4 / 8 (0 = by launch size)
     bool gftt_bitonic;        // VOFE_GFTT_SORT=bitonic
