@@ -1129,6 +1129,11 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #else
 #define LK_X2_ATTR
 #endif
+// A/B builds only: extra dynamic LDS per workgroup of the shipped x2 launch caps its wavefronts per SIMD below what its
+// registers allow (leaving registers for another stream's kernels); profiles/r03_lk_experiments.txt has what that measured.
+#ifndef LK_X2_LDS_EXTRA
+#define LK_X2_LDS_EXTRA 0
+#endif
 template <int PPW, bool PRE>
 __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
     extern __shared__ unsigned lds[];
@@ -1253,7 +1258,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     else if (x2_ok && force && force[0] == 'x' && force[1] == '2' && force[2] == 'p')          // "x2p": the prefetching variant (3 waves per SIMD)
         hipLaunchKernelGGL((lk_track_kernel_x2<2, true>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
-        hipLaunchKernelGGL((lk_track_kernel_x2<2, false>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+        hipLaunchKernelGGL((lk_track_kernel_x2<2, false>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4 + LK_X2_LDS_EXTRA, st, a);
     else if (lp_ok && a.win_w == 21 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
         hipLaunchKernelGGL((lk_track_kernel_lp<7, 21>), dim3(a.n), dim3(64 * a.n_levels), lp_lds, st, a);
     else if (lp_ok && a.win_w == 11 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
