@@ -57,9 +57,9 @@ N_FRAMES = 8
 LK_PMC = {
     # (lk_track_kernel_x2<2, false>: 127 VGPRs, 4 wavefronts per SIMD; round 2's 150-VGPR kernel: 590.7e6 instructions in
     # 20955989.7 / 8 cycles = 0.220, profiles/r02_pmc_inst_v5.txt)
-    (64, 2000): {"valu_instr": 579912631.0, "cycles": 18953860.3 / 8, "fetch_kb": 1848286.6, "write_kb": 6511.0,
-                 "kernel_source": ("lk.hip", "a2122ffb33864e06"),
-                 "source": "profiles/r03_pmc_inst_v1.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v1.txt, r03_pmc_write_v1.txt"},
+    (64, 2000): {"valu_instr": 579912631.0, "cycles": 19008023.7 / 8, "fetch_kb": 1848527.6, "write_kb": 6512.9,
+                 "kernel_source": ("lk.hip", "a6cb357c05e65d40"),
+                 "source": "profiles/r03_pmc_inst_v2.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v2.txt, r03_pmc_write_v2.txt"},
 }
 # corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
 # instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
