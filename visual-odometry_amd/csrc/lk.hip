@@ -15,6 +15,8 @@
 // reduced with DPP row rotations + 4 readlanes.  Not HBM- or MFMA-bound: gather + VALU + LDS.
 #include <cmath>
 
+#include <cstring>
+
 #include "vofe_internal.h"
 
 namespace {
@@ -41,6 +43,7 @@ struct LKArgs {
     int groups, rows_per_group;
     int max_count, flags, fb;
     float min_eig_thr, fb_thresh;
+    float min_eig_num;         // smallest x with fl(x / (2 win_w win_h)) >= min_eig_thr: "minEig < thr" == "numerator < min_eig_num"
     double eps2;
     float eps2_lo, eps2_hi;    // f32 brackets of eps2 for the cheap convergence pre-test
     int rh, rs;                // LDS region: rows, row stride in entries (8 * segs)
@@ -53,6 +56,15 @@ __device__ __forceinline__ int floor_i(float v) {
     return __builtin_fabsf(v) < 1073741824.f ? i : INT_MIN;              // NaN / huge -> INT_MIN (fails every bounds test)
 }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
+// 1 / 2^level, exactly, from the exponent field (the IEEE division sequence of level_scale(level) is twelve instructions)
+#ifndef LK_OPT2
+#define LK_OPT2 6
+#endif
+#if LK_OPT2 & 2
+__device__ __forceinline__ float level_scale(int level) { return __builtin_bit_cast(float, (127 - level) << 23); }
+#else
+__device__ __forceinline__ float level_scale(int level) { return 1.0f / (float)(1 << level); }
+#endif
 
 // signed 2-way dot product: pixel pairs (0..255) x weight pairs.  Signed on purpose: the fourth
 // bilinear weight 16384 - w00 - w01 - w10 can come out as -1 after rounding.
@@ -123,6 +135,37 @@ __device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int 
     q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
     q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
     return q;
+}
+
+// The same weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy).  The factor 2^14 is applied to the
+// x terms first: scaling by a power of two is exact, so fl(fl(u v) 2^14) == fl((u 2^14) v) bit for bit, and five
+// multiplications replace six.
+__device__ __forceinline__ Wts bilinear_weights_ab(float a, float b) {
+    const float u = 1.f - a, v = 1.f - b;
+    const float u14 = u * (float)(1 << W_BITS), a14 = a * (float)(1 << W_BITS);
+    Wts q;
+    q.w00 = round_i(u14 * v);
+    q.w01 = round_i(a14 * v);
+    q.w10 = round_i(u14 * b);
+    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
+    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
+    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
+    return q;
+}
+// two partial sums at once: both inside [-2^25, 2^25) on every lane (wave-uniform answer)
+__device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {          // the reference's expression order, from the fractions
+    Wts q;
+    q.w00 = round_i((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
+    q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
+    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
+    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
+    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
+    return q;
+}
+__device__ __forceinline__ bool partials_fit2(int a, int b) {
+    const unsigned m = (unsigned)(a + (1 << 25)) | (unsigned)(b + (1 << 25));
+    return !__any(m >= (1u << 26));
 }
 
 // Explicit global-address-space loads at byte alignment: the plane pointers come out of a table in
@@ -267,7 +310,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         STAMP_BEGIN();
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
-        const float sc = 1.0f / (float)(1 << level);
+        const float sc = level_scale(level);
         float ppx = px * sc, ppy = py * sc;
         float npx, npy;
         if (level == top) {
@@ -567,7 +610,7 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
     // ---- this level's fixed part (all levels at once) ----------------------------------------------------------
     const VofeLevel A = LA[level];
     const VofeLevel B = LB[level];
-    const float sc = 1.0f / (float)(1 << level);
+    const float sc = level_scale(level);
     float ppx = px * sc, ppy = py * sc;
     const float tpx = ppx, tpy = ppy;                 // the walk's start at the top level
     ppx -= hx; ppy -= hy;
@@ -882,7 +925,12 @@ __device__ __forceinline__ void stage_load(Stage<PPW>& s, gbase_t Jb, unsigned s
         s.nb[k] = 0u;
         if (t < TASKS) {
             const int gy = min(max(ry0 + row, ymin), ymax);
+            // (rows and pitch are far below 2^24: v_mad_u32_u24 instead of the 64-bit multiply-add)
+#if LK_OPT2 & 1
+            const unsigned off = slot_off + __umul24((unsigned)(gy + W), (unsigned)B.pitch) + (unsigned)(rx0 + PADX + seg * 8);
+#else
             const unsigned off = slot_off + (unsigned)((gy + W) * B.pitch + (rx0 + PADX + seg * 8));
+#endif
             const u32x3 q = gload_u96(Jb, off);
             s.v[k] = make_uint2(q.x, q.y);
             s.nb[k] = q.z;
@@ -936,7 +984,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
     for (int level = top; level >= 0; --level) {
         const VofeLevel A = LA[level];
         const VofeLevel B = LB[level];
-        const float sc = 1.0f / (float)(1 << level);
+        const float sc = level_scale(level);
         float ppx = px * sc, ppy = py * sc;
         float npx, npy;
         if (level == top) {
@@ -1028,9 +1076,17 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         const float FLT_SCALE = 1.f / (float)(1 << 20);
         const float A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
         float Dd = A11 * A22 - A12 * A12;
+        // the threshold test on the numerator (correctly rounded division is monotone; the host found the matching bound), the
+        // division itself only where the quotient is an output
+#if LK_OPT2 & 4
+        const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+        if (flags & 8) err = eigNum / (float)(2 * w * h);
+        if (eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f) {
+#else
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
         if (flags & 8) err = minEig;
         if (minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f) {
+#endif
             if (level == 0) status = 0;
             continue;
         }
@@ -1044,19 +1100,35 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             lds_order();
         }
         const int nine = 9;
+        // Fast test of an iteration's window position: while the staged region lies where no window position inside it can
+        // leave the image ("safe"), being inside the region (two unsigned compares on the offsets the LDS address needs anyway)
+        // implies the bounds test.  A NaN position can only enter at the start of a level (every update below is finite) and
+        // takes the full test, like positions near the image border and the first iteration after a level without a region.
+#ifndef LK_OPT
+#define LK_OPT 5
+#endif
+        bool fast = (LK_OPT & 1) && staged && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h &&
+                    !__builtin_isunordered(npx, npy);
         for (int j = 0; j < a.max_count; ++j) {
-            const int inx = floor_i(npx), iny = floor_i(npy);
-            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
-                if (level == 0) status = 0;
-                break;
-            }
-            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
-                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                restage<PPW>(region, Jb, jslot, B, rx0, ry0, l32);
-                staged = true;
+            const float flx = __builtin_floorf(npx), fly = __builtin_floorf(npy);
+            int inx = (int)flx, iny = (int)fly;
+            if (!(fast && (unsigned)(inx - rx0) <= (unsigned)(2 * LK_MARGIN) && (unsigned)(iny - ry0) <= (unsigned)(2 * LK_MARGIN))) {
+                inx = floor_i(npx); iny = floor_i(npy);
+                if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                    if (level == 0) status = 0;
+                    break;
+                }
+                if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                    rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                    restage<PPW>(region, Jb, jslot, B, rx0, ry0, l32);
+                    staged = true;
+                    fast = (LK_OPT & 1) && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h;
+                }
             }
             ++n_it;
-            const Wts q = bilinear_weights(npx, npy, inx, iny);
+            // (float)inx == floor(npx) here (|npx| < 2^24 inside the image), so the fractional parts come from the floors
+            const Wts q = (LK_OPT & 2) ? bilinear_weights_ab(npx - flx, npy - fly) :
+                          ((LK_OPT & 8) ? bilinear_weights_frac(npx - flx, npy - fly) : bilinear_weights(npx, npy, inx, iny));
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1075,7 +1147,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 }
             }
             float fb1, fb2;
-            if (partials_fit(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
+            if ((LK_OPT & 4) ? partials_fit2(b1, b2) : partials_fit(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
             else { fb1 = half_sum_to_float<PPW>(b1, partner_addr); fb2 = half_sum_to_float<PPW>(b2, partner_addr); }
             fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * Dd;
@@ -1197,6 +1269,27 @@ __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
     }
 }
 
+// Smallest float x (in the order -inf < ... < +inf) with fl(x / c) >= thr, c > 0: fl(x / c) < thr exactly when x < that bound,
+// because correctly rounded division by a positive constant is monotone in x.  NaN threshold: the test is never true -> NaN.
+// Bisection over the floats' order-preserving integer image; the host's float division is the same IEEE operation as the
+// kernels' division sequence.
+inline unsigned ordered_bits(float f) { unsigned u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+inline float from_ordered_bits(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; }
+float min_eig_numerator_bound(float thr, float c) {
+    if (thr != thr) return thr;
+    const float inf = __builtin_inff();
+    volatile float q = inf / c;
+    if (!(q >= thr)) return __builtin_nanf("");           // not even +inf passes (thr = NaN is handled above; unreachable otherwise)
+    unsigned lo = ordered_bits(-inf), hi = ordered_bits(inf);           // invariant: hi passes; everything below lo fails
+    while (lo < hi) {
+        const unsigned mid = lo + (hi - lo) / 2;
+        volatile float v = from_ordered_bits(mid);
+        volatile float r = v / c;
+        if (r >= thr) hi = mid; else lo = mid + 1;
+    }
+    return from_ordered_bits(lo);
+}
+
 template <int R, int WC = 0>
 void launch_r(const LKArgs& a, size_t lds_bytes, hipStream_t st) {
     hipLaunchKernelGGL((lk_track_kernel<R, WC>), dim3(a.n), dim3(64), lds_bytes, st, a);
@@ -1225,6 +1318,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
     if (a.rows_per_group > 64) { vofe_set_error("vofe_lk_track: winSize %dx%d too tall (max 64 rows per lane)", a.win_w, a.win_h); return VOFE_E_UNSUPPORTED; }
     a.max_count = max_count; a.flags = flags; a.fb = fb;
     a.min_eig_thr = min_eig_thr; a.fb_thresh = fb_thresh; a.eps2 = eps2;
+    a.min_eig_num = min_eig_numerator_bound(min_eig_thr, (float)(2 * a.win_w * a.win_h));
     a.eps2_lo = nextafterf((float)(eps2 * (1.0 - 1e-6)), -1.f);
     a.eps2_hi = nextafterf((float)(eps2 * (1.0 + 1e-6)), 1e30f);
     a.counters = ctx->lk_counters;
