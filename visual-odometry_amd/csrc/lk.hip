@@ -57,14 +57,7 @@ __device__ __forceinline__ int floor_i(float v) {
 }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
 // 1 / 2^level, exactly, from the exponent field (the IEEE division sequence of level_scale(level) is twelve instructions)
-#ifndef LK_OPT2
-#define LK_OPT2 6
-#endif
-#if LK_OPT2 & 2
 __device__ __forceinline__ float level_scale(int level) { return __builtin_bit_cast(float, (127 - level) << 23); }
-#else
-__device__ __forceinline__ float level_scale(int level) { return 1.0f / (float)(1 << level); }
-#endif
 
 // signed 2-way dot product: pixel pairs (0..255) x weight pairs.  Signed on purpose: the fourth
 // bilinear weight 16384 - w00 - w01 - w10 can come out as -1 after rounding.
@@ -137,30 +130,17 @@ __device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int 
     return q;
 }
 
-// The same weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy).  The factor 2^14 is applied to the
-// x terms first: scaling by a power of two is exact, so fl(fl(u v) 2^14) == fl((u 2^14) v) bit for bit, and five
-// multiplications replace six.
-__device__ __forceinline__ Wts bilinear_weights_ab(float a, float b) {
-    const float u = 1.f - a, v = 1.f - b;
-    const float u14 = u * (float)(1 << W_BITS), a14 = a * (float)(1 << W_BITS);
-    Wts q;
-    q.w00 = round_i(u14 * v);
-    q.w01 = round_i(a14 * v);
-    q.w10 = round_i(u14 * b);
-    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
-    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
-    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
-    return q;
-}
-// two partial sums at once: both inside [-2^25, 2^25) on every lane (wave-uniform answer)
-__device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {          // the reference's expression order, from the fractions
+// weights packed by v_cvt_pk_i16_i32 (values are within int16: one instruction per pair instead of shift + and-or)
+__device__ __forceinline__ unsigned pack_i16(int lo, int hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
+// The weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy) (same expressions, same order as above)
+__device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {
     Wts q;
     q.w00 = round_i((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
     q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
     q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
     q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
-    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
-    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
+    q.w0 = pack_i16(q.w00, q.w01);
+    q.w1 = pack_i16(q.w10, q.w11);
     return q;
 }
 __device__ __forceinline__ bool partials_fit2(int a, int b) {
@@ -926,11 +906,7 @@ __device__ __forceinline__ void stage_load(Stage<PPW>& s, gbase_t Jb, unsigned s
         if (t < TASKS) {
             const int gy = min(max(ry0 + row, ymin), ymax);
             // (rows and pitch are far below 2^24: v_mad_u32_u24 instead of the 64-bit multiply-add)
-#if LK_OPT2 & 1
             const unsigned off = slot_off + __umul24((unsigned)(gy + W), (unsigned)B.pitch) + (unsigned)(rx0 + PADX + seg * 8);
-#else
-            const unsigned off = slot_off + (unsigned)((gy + W) * B.pitch + (rx0 + PADX + seg * 8));
-#endif
             const u32x3 q = gload_u96(Jb, off);
             s.v[k] = make_uint2(q.x, q.y);
             s.nb[k] = q.z;
@@ -971,7 +947,9 @@ __device__ __forceinline__ void restage(unsigned* region, gbase_t Jb, unsigned s
 // wavefront) at the price of the 12 staging registers being live across the template set-up -- 150 VGPRs = 3 wavefronts per
 // SIMD.  Without it the region is loaded after the minimum-eigenvalue test: 127 VGPRs = 4 wavefronts per SIMD, which hide the
 // latency ACROSS wavefronts instead (and a level that fails the test stages nothing).
-template <int PPW, bool PRE>
+// CNT: the instance that feeds the optional work counters (vofe_lk_set_counters: point-levels entered, iterations); the
+// instance without them carries neither the two registers nor the per-iteration increment.
+template <int PPW, bool PRE, bool CNT>
 __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restrict__ LA, const VofeLevel* __restrict__ LB,
                                        int slotA, int slotB, float px, float py, float& outx, float& outy,
                                        int& status, float& err, int flags, unsigned* region, int l32, int partner_addr,
@@ -998,7 +976,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
-        ++n_lv;
+        if (CNT) ++n_lv;
         const gbase_t Jb = plane_base(B.I, B.pitch);
         const unsigned jslot = (unsigned)slotB * (unsigned)B.slot_stride;
         bool staged = false;
@@ -1078,19 +1056,14 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         float Dd = A11 * A22 - A12 * A12;
         // the threshold test on the numerator (correctly rounded division is monotone; the host found the matching bound), the
         // division itself only where the quotient is an output
-#if LK_OPT2 & 4
         const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
         if (flags & 8) err = eigNum / (float)(2 * w * h);
         if (eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f) {
-#else
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
-        if (flags & 8) err = minEig;
-        if (minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f) {
-#endif
             if (level == 0) status = 0;
             continue;
         }
         Dd = 1.f / Dd;
+        const float Dds = Dd * FLT_SCALE;
         npx -= hx; npy -= hy;
         float pdx = 0.f, pdy = 0.f;
         if (staged) {
@@ -1104,10 +1077,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         // leave the image ("safe"), being inside the region (two unsigned compares on the offsets the LDS address needs anyway)
         // implies the bounds test.  A NaN position can only enter at the start of a level (every update below is finite) and
         // takes the full test, like positions near the image border and the first iteration after a level without a region.
-#ifndef LK_OPT
-#define LK_OPT 5
-#endif
-        bool fast = (LK_OPT & 1) && staged && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h &&
+        bool fast = staged && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h &&
                     !__builtin_isunordered(npx, npy);
         for (int j = 0; j < a.max_count; ++j) {
             const float flx = __builtin_floorf(npx), fly = __builtin_floorf(npy);
@@ -1122,13 +1092,12 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                     rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
                     restage<PPW>(region, Jb, jslot, B, rx0, ry0, l32);
                     staged = true;
-                    fast = (LK_OPT & 1) && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h;
+                    fast = rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h;
                 }
             }
-            ++n_it;
+            if (CNT) ++n_it;
             // (float)inx == floor(npx) here (|npx| < 2^24 inside the image), so the fractional parts come from the floors
-            const Wts q = (LK_OPT & 2) ? bilinear_weights_ab(npx - flx, npy - fly) :
-                          ((LK_OPT & 8) ? bilinear_weights_frac(npx - flx, npy - fly) : bilinear_weights(npx, npy, inx, iny));
+            const Wts q = bilinear_weights_frac(npx - flx, npy - fly);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1147,11 +1116,11 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 }
             }
             float fb1, fb2;
-            if ((LK_OPT & 4) ? partials_fit2(b1, b2) : partials_fit(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
+            if (partials_fit2(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
             else { fb1 = half_sum_to_float<PPW>(b1, partner_addr); fb2 = half_sum_to_float<PPW>(b2, partner_addr); }
-            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
-            const float dx = (A12 * fb2 - A22 * fb1) * Dd;
-            const float dy = (A12 * fb1 - A11 * fb2) * Dd;
+            // FLT_SCALE = 2^-20 commutes with every rounding here, so it is folded into the reciprocal once per level
+            const float dx = (A12 * fb2 - A22 * fb1) * Dds;
+            const float dy = (A12 * fb1 - A11 * fb2) * Dds;
             npx += dx; npy += dy;
             outx = npx + hx; outy = npy + hy;
             const float d2 = dx * dx + dy * dy;
@@ -1206,7 +1175,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
 #ifndef LK_X2_LDS_EXTRA
 #define LK_X2_LDS_EXTRA 0
 #endif
-template <int PPW, bool PRE>
+template <int PPW, bool PRE, bool CNT>
 __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
     extern __shared__ unsigned lds[];
     constexpr int GL = x2::Cfg<PPW>::GL, NS = x2::Cfg<PPW>::NS;
@@ -1244,7 +1213,7 @@ __global__ __launch_bounds__(64) LK_X2_ATTR void lk_track_kernel_x2(LKArgs a) {
         float qx = dir ? fx : p.x, qy = dir ? fy : p.y;
         float ox = dir ? 0.f : fx, oy = dir ? 0.f : fy, e = 0.f;
         int s = 1;
-        x2::lk_one<PPW, PRE>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0,
+        x2::lk_one<PPW, PRE, CNT>(a, LA, LB, sa, sb, qx, qy, ox, oy, s, e, dir ? LK_NO_ERR : a.flags, region, l32, partner_addr, sx, sy0,
                         sok, n_lv, n_it);
         if (dir == 0) { fx = ox; fy = oy; st = s; er = e; }
         else { bx = ox; by = oy; }
@@ -1348,11 +1317,14 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
                        !(flags & 8) && !(force && force[0] != 'l');
     const size_t lp_lds = ((size_t)LK_LP_HAND + (size_t)a.n_levels * a.rs * a.rh) * 4;
     if (x2_ok && force && force[0] == 'x' && force[1] == '4')
-        hipLaunchKernelGGL((lk_track_kernel_x2<4, true>), dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
+        hipLaunchKernelGGL((lk_track_kernel_x2<4, true, true>), dim3((a.n + 3) / 4), dim3(64), (size_t)4 * x2::REGION * 4, st, a);
     else if (x2_ok && force && force[0] == 'x' && force[1] == '2' && force[2] == 'p')          // "x2p": the prefetching variant (3 waves per SIMD)
-        hipLaunchKernelGGL((lk_track_kernel_x2<2, true>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
+        hipLaunchKernelGGL((lk_track_kernel_x2<2, true, true>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4, st, a);
     else if (x2_ok && ((force && force[0] == 'x' && force[1] == '2') || (!force && n >= LK_X2_MIN_POINTS)))
-        hipLaunchKernelGGL((lk_track_kernel_x2<2, false>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4 + LK_X2_LDS_EXTRA, st, a);
+    {
+        if (a.counters) hipLaunchKernelGGL((lk_track_kernel_x2<2, false, true>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4 + LK_X2_LDS_EXTRA, st, a);
+        else hipLaunchKernelGGL((lk_track_kernel_x2<2, false, false>), dim3((a.n + 1) / 2), dim3(64), (size_t)2 * x2::REGION * 4 + LK_X2_LDS_EXTRA, st, a);
+    }
     else if (lp_ok && a.win_w == 21 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
         hipLaunchKernelGGL((lk_track_kernel_lp<7, 21>), dim3(a.n), dim3(64 * a.n_levels), lp_lds, st, a);
     else if (lp_ok && a.win_w == 11 && ((force && force[0] == 'l') || (!force && n <= LK_LP_MAX_POINTS)))
