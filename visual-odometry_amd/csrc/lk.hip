@@ -135,9 +135,13 @@ __device__ __forceinline__ unsigned pack_i16(int lo, int hi) { return __builtin_
 // The weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy) (same expressions, same order as above)
 __device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {
     Wts q;
-    q.w00 = round_i((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
-    q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
+    // the factor 2^14 applied to the x terms first: scaling by a power of two commutes with rounding, fl(fl(u v) 2^14) ==
+    // fl((u 2^14) v) bit for bit, and five multiplications replace six
+    const float u = 1.f - a, v = 1.f - b;
+    const float u14 = u * (float)(1 << W_BITS), a14 = a * (float)(1 << W_BITS);
+    q.w00 = round_i(u14 * v);
+    q.w01 = round_i(a14 * v);
+    q.w10 = round_i(u14 * b);
     q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
     q.w0 = pack_i16(q.w00, q.w01);
     q.w1 = pack_i16(q.w10, q.w11);
@@ -379,13 +383,15 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         const float FLT_SCALE = 1.f / (float)(1 << 20);
         const float A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
         float Dd = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
-        if (flags & 8) err = minEig;
-        if (minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f) {
+        // (threshold test on the numerator, division only where the quotient is an output: see LKArgs::min_eig_num)
+        const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+        if (flags & 8) err = eigNum / (float)(2 * w * h);
+        if (eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
         Dd = 1.f / Dd;
+        const float Dds = Dd * FLT_SCALE;          // 2^-20 commutes with every rounding below
         STAMP_END(1);
         npx -= hx; npy -= hy;
         float pdx = 0.f, pdy = 0.f;
@@ -397,22 +403,31 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         }
         STAMP_END(2);
         const int nine = 9;
+        // fast position test while the staged region is "safe" (no window position inside it leaves the image) and the
+        // position is no NaN (one can only enter at the start of a level): being inside the region implies the bounds test
+        bool fast = staged && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h &&
+                    !__builtin_isunordered(npx, npy);
         for (int j = 0; j < a.max_count; ++j) {
-            const int inx = floor_i(npx), iny = floor_i(npy);
-            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
-                if (level == 0) status = 0;
-                break;
-            }
-            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
-                __syncthreads();
-                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
-                staged = true;
-                __syncthreads();
+            const float flx = __builtin_floorf(npx), fly = __builtin_floorf(npy);
+            int inx = (int)flx, iny = (int)fly;
+            if (!(fast && (unsigned)(inx - rx0) <= (unsigned)(2 * LK_MARGIN) && (unsigned)(iny - ry0) <= (unsigned)(2 * LK_MARGIN))) {
+                inx = floor_i(npx); iny = floor_i(npy);
+                if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                    if (level == 0) status = 0;
+                    break;
+                }
+                if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                    __syncthreads();
+                    rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                    stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                    staged = true;
+                    __syncthreads();
+                    fast = rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h;
+                }
             }
             ++n_it;
             STAMP_END(6);
-            const Wts q = bilinear_weights(npx, npy, inx, iny);
+            const Wts q = bilinear_weights_frac(npx - flx, npy - fly);
             const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
             unsigned P[R + 1];
 #pragma unroll
@@ -429,12 +444,11 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
             }
             STAMP_END(3);
             float fb1, fb2;
-            if (partials_fit(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
+            if (partials_fit2(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
             else { fb1 = wave_sum_to_float(b1); fb2 = wave_sum_to_float(b2); }
-            fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
             STAMP_END(4);
-            const float dx = (A12 * fb2 - A22 * fb1) * Dd;
-            const float dy = (A12 * fb1 - A11 * fb2) * Dd;
+            const float dx = (A12 * fb2 - A22 * fb1) * Dds;
+            const float dy = (A12 * fb1 - A11 * fb2) * Dds;
             npx += dx; npy += dy;
             outx = npx + hx; outy = npy + hy;
             STAMP_END(5);
@@ -888,6 +902,21 @@ __device__ __forceinline__ float half_sum_to_float(int v, int partner_addr) {
     return (float)((long long)hi * 65536 + (long long)lo);
 }
 
+// Both sums of an iteration in ONE reduction: lanes 0-7 of every DPP row reduce b1, lanes 8-15 reduce b2 (`hi8` = lane & 8).
+// own = the group's total of the sum this lane's half-row reduced, other = the total of the other sum.  Integer adds: exact in
+// any order, same totals as two half_sum calls; 8 instructions instead of 12.
+template <int PPW>
+__device__ __forceinline__ void half_sum_pair(int b1, int b2, bool hi8, int partner_addr, int& own, int& other) {
+    const int m = hi8 ? b2 : b1, m2 = hi8 ? b1 : b2;
+    int z = m + __builtin_amdgcn_update_dpp(0, m2, 0x128, 0xF, 0xF, false);      // row_ror:8: the other half-row's lane of the same sum
+    z += __builtin_amdgcn_update_dpp(0, z, 0x141, 0xF, 0xF, false);              // row_half_mirror
+    z += __builtin_amdgcn_update_dpp(0, z, 0xB1, 0xF, 0xF, false);               // quad_perm:[1,0,3,2]
+    z += __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xF, 0xF, false);               // quad_perm:[2,3,0,1]
+    if (PPW == 2) z += __builtin_amdgcn_ds_bpermute(partner_addr, z);
+    own = z;
+    other = __builtin_amdgcn_update_dpp(0, z, 0x128, 0xF, 0xF, false);
+}
+
 template <int PPW> struct Stage { uint2 v[Cfg<PPW>::TB]; unsigned nb[Cfg<PPW>::TB]; };
 // Addresses are a wave-uniform base (the plane's first reachable byte: row -W, column -PADX of slot 0) plus an
 // unsigned 32-bit lane offset that includes the half's slot, so loads keep the saddr form although the two
@@ -1064,6 +1093,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         }
         Dd = 1.f / Dd;
         const float Dds = Dd * FLT_SCALE;
+        // lanes 0-7 of a DPP row own the b1 total (dx = A12 other - A22 own, dy = A12 own - A11 other), lanes 8-15 the b2 total
+        const bool hi8 = (l32 & 8) != 0;
+        const float cxo = hi8 ? A12 : -A22, cxt = hi8 ? -A22 : A12, cyo = hi8 ? -A11 : A12, cyt = hi8 ? A12 : -A11;
         npx -= hx; npy -= hy;
         float pdx = 0.f, pdy = 0.f;
         if (staged) {
@@ -1115,12 +1147,20 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                     b2 = sdot2((unsigned)dp, IYp[s][qd], b2);
                 }
             }
-            float fb1, fb2;
-            if (partials_fit2(b1, b2)) { fb1 = (float)half_sum<PPW>(b1, partner_addr); fb2 = (float)half_sum<PPW>(b2, partner_addr); }
-            else { fb1 = half_sum_to_float<PPW>(b1, partner_addr); fb2 = half_sum_to_float<PPW>(b2, partner_addr); }
-            // FLT_SCALE = 2^-20 commutes with every rounding here, so it is folded into the reciprocal once per level
-            const float dx = (A12 * fb2 - A22 * fb1) * Dds;
-            const float dy = (A12 * fb1 - A11 * fb2) * Dds;
+            // FLT_SCALE = 2^-20 commutes with every rounding here, so it is folded into the reciprocal once per level.  The two
+            // products of dx (and of dy) are added in either order (a - b == a + (-b), addition commutes), so each lane takes
+            // them as own / other with the coefficients its half-row was given above.
+            float fo, ft;
+            if (partials_fit2(b1, b2)) {
+                int own, other;
+                half_sum_pair<PPW>(b1, b2, hi8, partner_addr, own, other);
+                fo = (float)own; ft = (float)other;
+            } else {
+                const float fb1 = half_sum_to_float<PPW>(b1, partner_addr), fb2 = half_sum_to_float<PPW>(b2, partner_addr);
+                fo = hi8 ? fb2 : fb1; ft = hi8 ? fb1 : fb2;
+            }
+            const float dx = (cxt * ft + cxo * fo) * Dds;
+            const float dy = (cyt * ft + cyo * fo) * Dds;
             npx += dx; npy += dy;
             outx = npx + hx; outy = npy + hy;
             const float d2 = dx * dx + dy * dy;
