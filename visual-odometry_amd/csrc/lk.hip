@@ -678,9 +678,10 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
         const float FLT_SCALE0 = 1.f / (float)(1 << 20);
         A11 = fA11 * FLT_SCALE0; A12 = fA12 * FLT_SCALE0; A22 = fA22 * FLT_SCALE0;
         Dd = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * w * h);
-        eig_ok = !(minEig < a.min_eig_thr || Dd < 1.1920928955078125e-07f);
-        Dd = 1.f / Dd;
+        // (threshold test on the numerator: see LKArgs::min_eig_num; this kernel never reports the quotient)
+        const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+        eig_ok = !(eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f);
+        Dd = 1.f / Dd * FLT_SCALE0;                    // 2^-20 folded in: it commutes with every rounding of the update
         if (staged) {                                  // (uniform) the region guessed above; this wave's reads of the other direction are done
             wave_lds_order();
             stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
@@ -708,22 +709,30 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
                     npx -= hx; npy -= hy;
                     float pdx = 0.f, pdy = 0.f;
                     bool lost = false;
+                    // fast position test, as in lk_one: inside a "safe" staged region nothing else needs testing
+                    bool fast = staged && rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h &&
+                                !__builtin_isunordered(npx, npy);
                     for (int j = 0; j < a.max_count; ++j) {
-                        const int inx = floor_i(npx), iny = floor_i(npy);
-                        if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
-                            if (level == 0) status = 0;
-                            lost = true;
-                            break;
-                        }
-                        if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
-                            wave_lds_order();
-                            rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
-                            stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
-                            staged = true;
-                            wave_lds_order();
+                        const float flx = __builtin_floorf(npx), fly = __builtin_floorf(npy);
+                        int inx = (int)flx, iny = (int)fly;
+                        if (!(fast && (unsigned)(inx - rx0) <= (unsigned)(2 * LK_MARGIN) && (unsigned)(iny - ry0) <= (unsigned)(2 * LK_MARGIN))) {
+                            inx = floor_i(npx); iny = floor_i(npy);
+                            if (inx < -w || inx >= B.w || iny < -h || iny >= B.h) {
+                                if (level == 0) status = 0;
+                                lost = true;
+                                break;
+                            }
+                            if (!staged || inx < rx0 || inx > rx0 + 2 * LK_MARGIN || iny < ry0 || iny > ry0 + 2 * LK_MARGIN) {
+                                wave_lds_order();
+                                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                                stage_rest<WIDE>(lds, J0, B, w, h, rx0, ry0, segs, inv_segs, tasks, 0, lane);
+                                staged = true;
+                                wave_lds_order();
+                                fast = rx0 >= -w && rx0 + 2 * LK_MARGIN < B.w && ry0 >= -h && ry0 + 2 * LK_MARGIN < B.h;
+                            }
                         }
                         ++n_it;
-                        const Wts q = bilinear_weights(npx, npy, inx, iny);
+                        const Wts q = bilinear_weights_frac(npx - flx, npy - fly);
                         const unsigned* lp = lds + (iny - ry0 + y0) * rs + (inx - rx0) + x;
                         unsigned P[R + 1];
 #pragma unroll
@@ -738,9 +747,8 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
                             b2 = sdot2((unsigned)dp, IYp[qd], b2);
                         }
                         float fb1, fb2;
-                        if (partials_fit(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
+                        if (partials_fit2(b1, b2)) { fb1 = (float)wave_sum_small(b1); fb2 = (float)wave_sum_small(b2); }
                         else { fb1 = wave_sum_to_float(b1); fb2 = wave_sum_to_float(b2); }
-                        fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
                         const float dx = (A12 * fb2 - A22 * fb1) * Dd;
                         const float dy = (A12 * fb1 - A11 * fb2) * Dd;
                         npx += dx; npy += dy;
