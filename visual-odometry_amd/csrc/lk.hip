@@ -118,25 +118,14 @@ __device__ __forceinline__ bool partials_fit(int a, int b, int c = 0) {
 }
 
 struct Wts { unsigned w0, w1; int w00, w01, w10, w11; };
-__device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int iy) {
-    const float a = fx - (float)ix, b = fy - (float)iy;
-    Wts q;
-    q.w00 = round_i((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    q.w01 = round_i(a * (1.f - b) * (float)(1 << W_BITS));
-    q.w10 = round_i((1.f - a) * b * (float)(1 << W_BITS));
-    q.w11 = (1 << W_BITS) - q.w00 - q.w01 - q.w10;
-    q.w0 = ((unsigned)q.w00 & 0xffffu) | ((unsigned)q.w01 << 16);
-    q.w1 = ((unsigned)q.w10 & 0xffffu) | ((unsigned)q.w11 << 16);
-    return q;
-}
-
 // weights packed by v_cvt_pk_i16_i32 (values are within int16: one instruction per pair instead of shift + and-or)
 __device__ __forceinline__ unsigned pack_i16(int lo, int hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
-// The weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy) (same expressions, same order as above)
+// The 14-bit bilinear weights from the fractional parts a = fx - floor(fx), b = fy - floor(fy):
+//   w00 = round((1-a)(1-b) 2^14), w01 = round(a (1-b) 2^14), w10 = round((1-a) b 2^14), w11 = 2^14 - w00 - w01 - w10.
+// The factor 2^14 is applied to the x terms first: scaling by a power of two commutes with rounding, fl(fl(u v) 2^14) ==
+// fl((u 2^14) v) bit for bit, and five multiplications replace six.
 __device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {
     Wts q;
-    // the factor 2^14 applied to the x terms first: scaling by a power of two commutes with rounding, fl(fl(u v) 2^14) ==
-    // fl((u 2^14) v) bit for bit, and five multiplications replace six
     const float u = 1.f - a, v = 1.f - b;
     const float u14 = u * (float)(1 << W_BITS), a14 = a * (float)(1 << W_BITS);
     q.w00 = round_i(u14 * v);
@@ -146,6 +135,14 @@ __device__ __forceinline__ Wts bilinear_weights_frac(float a, float b) {
     q.w0 = pack_i16(q.w00, q.w01);
     q.w1 = pack_i16(q.w10, q.w11);
     return q;
+}
+__device__ __forceinline__ Wts bilinear_weights(float fx, float fy, int ix, int iy) {
+    return bilinear_weights_frac(fx - (float)ix, fy - (float)iy);
+}
+// the three partial sums of the structure tensor: a11, a22 >= 0 (sums of squares), a12 signed; all inside +-2^25
+__device__ __forceinline__ bool partials_fit_tensor(int a11, int a12, int a22) {
+    const unsigned m = (unsigned)(a12 + (1 << 25)) | ((unsigned)(a11 | a22) << 1);
+    return !__any(m >= (1u << 26));
 }
 __device__ __forceinline__ bool partials_fit2(int a, int b) {
     const unsigned m = (unsigned)(a + (1 << 25)) | (unsigned)(b + (1 << 25));
@@ -373,7 +370,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 a11 = sdot2((unsigned)xp, (unsigned)xp, a11); a12 = sdot2((unsigned)xp, (unsigned)yp, a12);
                 a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
             }
-            if (partials_fit(a11, a12, a22)) {
+            if (partials_fit_tensor(a11, a12, a22)) {
                 fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
             } else {
                 fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
@@ -669,7 +666,7 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
                 a11 = sdot2((unsigned)xp, (unsigned)xp, a11); a12 = sdot2((unsigned)xp, (unsigned)yp, a12);
                 a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
             }
-            if (partials_fit(a11, a12, a22)) {
+            if (partials_fit_tensor(a11, a12, a22)) {
                 fA11 = (float)wave_sum_small(a11); fA12 = (float)wave_sum_small(a12); fA22 = (float)wave_sum_small(a22);
             } else {
                 fA11 = wave_sum_to_float(a11); fA12 = wave_sum_to_float(a12); fA22 = wave_sum_to_float(a22);
@@ -1080,7 +1077,7 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                     a22 = sdot2((unsigned)yp, (unsigned)yp, a22);
                 }
             }
-            if (partials_fit(a11, a12, a22)) {
+            if (partials_fit_tensor(a11, a12, a22)) {
                 fA11 = (float)half_sum<PPW>(a11, partner_addr); fA12 = (float)half_sum<PPW>(a12, partner_addr);
                 fA22 = (float)half_sum<PPW>(a22, partner_addr);
             } else {
