@@ -55,11 +55,13 @@ N_FRAMES = 8
 # Every entry names the kernel source it was measured on by content hash: when that file has changed since, the counter
 # figures are not printed as a roofline fraction ("pmc_stale": true, VALU frac null) until the passes are re-run.
 LK_PMC = {
-    # (lk_track_kernel_x2<2, false>: 127 VGPRs, 4 wavefronts per SIMD; round 2's 150-VGPR kernel: 590.7e6 instructions in
-    # 20955989.7 / 8 cycles = 0.220, profiles/r02_pmc_inst_v5.txt)
-    (64, 2000): {"valu_instr": 579912631.0, "cycles": 19008023.7 / 8, "fetch_kb": 1848527.6, "write_kb": 6512.9,
-                 "kernel_source": ("lk.hip", "a6cb357c05e65d40"),
-                 "source": "profiles/r03_pmc_inst_v2.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v2.txt, r03_pmc_write_v2.txt"},
+    # (lk_track_kernel_x2<2, false, false>: 127 VGPRs, 4 wavefronts per SIMD, the counter-free instance.  History of this launch
+    # shape: round 2's 150-VGPR kernel 590.7e6 instructions in 20955989.7 / 8 cycles = 0.220 per cycle per SIMD
+    # (profiles/r02_pmc_inst_v5.txt); the 4-wave kernel 579.9e6 in 19008023.7 / 8 = 0.238 (r03_pmc_inst_v2.txt); after the
+    # instruction-count work on the iteration and the level prologue 498.8e6 in 17163872.7 / 8 = 0.227 (r03_pmc_inst_v3.txt))
+    (64, 2000): {"valu_instr": 498761763.0, "cycles": 17163872.7 / 8, "fetch_kb": 1832331.9, "write_kb": 6437.1,
+                 "kernel_source": ("lk.hip", "27f083446f728066"),
+                 "source": "profiles/r03_pmc_inst_v3.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v3.txt, r03_pmc_write_v3.txt"},
 }
 # corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
 # instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
@@ -555,8 +557,10 @@ def run_rank(args):
                                            "v_mad_i32_i24, v_add3, DPP adds: 4.1-4.2 cycles each in isolation, "
                                            "profiles/r01_ubench_valu_rates.txt), so the mix allows ~0.24 instr/cycle/SIMD; "
                                            "round 3: the search-region loads moved behind the minimum-eigenvalue test, 150 -> 127 VGPRs = 4 "
-                                           "instead of 3 wavefronts per SIMD: 0.220 -> 0.239 instr/cycle/SIMD, i.e. the launch now runs at "
-                                           "the bound its instruction mix sets",
+                                           "instead of 3 wavefronts per SIMD (0.220 -> 0.238 instr/cycle/SIMD: the launch runs at the bound "
+                                           "its instruction mix sets), then 14 % fewer instructions per launch (579.9 M -> 498.8 M: position "
+                                           "test of an iteration, packed reduction, weights, level prologue); the instructions removed were "
+                                           "mostly full-rate ones, so the rate reads 0.227 while the launch got 9 % shorter",
                          "hbm": hbm})
         else:
             roof.update(hbm)

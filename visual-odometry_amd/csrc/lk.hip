@@ -55,6 +55,9 @@ __device__ __forceinline__ int floor_i(float v) {
     const int i = (int)__builtin_floorf(v);                              // v_floor_f32 + v_cvt_i32_f32, exact below 2^30
     return __builtin_fabsf(v) < 1073741824.f ? i : INT_MIN;              // NaN / huge -> INT_MIN (fails every bounds test)
 }
+// floor to int32 by v_floor_f32 + v_cvt_i32_f32 alone: the conversion saturates (huge -> INT_MAX / INT_MIN) and maps NaN to 0;
+// callers that cannot tolerate the latter test for NaN themselves
+__device__ __forceinline__ int floor_sat(float v) { return (int)__builtin_floorf(v); }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
 // 1 / 2^level, exactly, from the exponent field (the IEEE division sequence of level_scale(level) is twelve instructions)
 __device__ __forceinline__ float level_scale(int level) { return __builtin_bit_cast(float, (127 - level) << 23); }
@@ -1005,8 +1008,10 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         } else { npx = outx * 2.f; npy = outy * 2.f; }
         outx = npx; outy = npy;
         ppx -= hx; ppy -= hy;
-        const int ipx = floor_i(ppx), ipy = floor_i(ppy);
-        if (ipx < -w || ipx >= A.w || ipy < -h || ipy >= A.h) {
+        // floor without floor_i's range select: v_cvt_i32_f32 saturates, so a huge coordinate still fails the bounds test, and
+        // the one value it maps into the image (NaN -> 0) is caught by the unordered compare
+        const int ipx = floor_sat(ppx), ipy = floor_sat(ppy);
+        if (__builtin_isunordered(ppx, ppy) || ipx < -w || ipx >= A.w || ipy < -h || ipy >= A.h) {
             if (level == 0) { status = 0; err = 0.f; }
             continue;
         }
@@ -1017,7 +1022,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         int rx0 = 0, ry0 = 0;
         Stage<PPW> pre;
         {
-            const int fx = floor_i(npx - hx), fy = floor_i(npy - hy);
+            // (a guess of where the iterations start: a NaN position stages a region nobody reads, the iteration's own test
+            // deals with it)
+            const int fx = floor_sat(npx - hx), fy = floor_sat(npy - hy);
             if (!(fx < -w || fx >= B.w || fy < -h || fy >= B.h)) {
                 rx0 = fx - LK_MARGIN; ry0 = fy - LK_MARGIN;
                 staged = true;
@@ -1045,6 +1052,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
                 unsigned pI[R + 1], pX[R + 1], pY[R + 1];
 #pragma unroll
                 for (int r = 0; r <= R; ++r) {
+                    // (the row step stays in the lane offset: moved into scalar bases -- one s_add pair per load, no VALU -- the
+                    // launch was 1 % slower)
                     const unsigned off = off0 + (unsigned)(r * A.pitch);
                     const unsigned two = gload_u16(Ib, off);
                     const uint2 dd = gload_u64(Db, off * 4u);
