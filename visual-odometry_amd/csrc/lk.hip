@@ -59,6 +59,20 @@ __device__ __forceinline__ int floor_i(float v) {
 // callers that cannot tolerate the latter test for NaN themselves
 __device__ __forceinline__ int floor_sat(float v) { return (int)__builtin_floorf(v); }
 __device__ __forceinline__ int round_i(float v) { return __float2int_rn(v); }
+// Correctly rounded 1 / d for d whose reciprocal is a normal number: the refinement steps of the IEEE division sequence the
+// compiler emits for 1.f / d (reciprocal estimate, one Newton step, quotient, two residual corrections), without its operand
+// scaling and special-case fix-up, which are identities on that range.  Used for the 2x2 determinant, which has passed the
+// FLT_EPSILON test and is bounded by the window's structure tensor (<= ~1e10).
+__device__ __forceinline__ float rcp_exact_normal(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;                                   // 1.0f * r
+    float rem = __builtin_fmaf(-d, q, 1.0f);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(rem, r, q);
+}
 // 1 / 2^level, exactly, from the exponent field (the IEEE division sequence of level_scale(level) is twelve instructions)
 __device__ __forceinline__ float level_scale(int level) { return __builtin_bit_cast(float, (127 - level) << 23); }
 
@@ -385,12 +399,12 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         float Dd = A11 * A22 - A12 * A12;
         // (threshold test on the numerator, division only where the quotient is an output: see LKArgs::min_eig_num)
         const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
-        if (flags & 8) err = eigNum / (float)(2 * w * h);
+        if (flags & 8) err = eigNum;               // (the numerator: divided once, behind the level loop)
         if (eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
-        Dd = 1.f / Dd;
+        Dd = rcp_exact_normal(Dd);
         const float Dds = Dd * FLT_SCALE;          // 2^-20 commutes with every rounding below
         STAMP_END(1);
         npx -= hx; npy -= hy;
@@ -495,6 +509,9 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         __syncthreads();     // all LDS reads of this level done before the next level restages
         STAMP_END(9);
     }
+    // OPTFLOW_LK_GET_MIN_EIGENVALS: err holds the numerator of the last level that reached the test (or the 0 of a level-0
+    // window outside the image); the one division it needs happens here instead of at every level
+    if (flags & 8) err = err / (float)(2 * w * h);
 }
 
 #undef LK_ROW
@@ -681,7 +698,7 @@ __device__ __forceinline__ void lk_lp_dir(const LKArgs& a, const VofeLevel* __re
         // (threshold test on the numerator: see LKArgs::min_eig_num; this kernel never reports the quotient)
         const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
         eig_ok = !(eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f);
-        Dd = 1.f / Dd * FLT_SCALE0;                    // 2^-20 folded in: it commutes with every rounding of the update
+        Dd = rcp_exact_normal(Dd) * FLT_SCALE0;        // (read only where eig_ok; 2^-20 folded in: it commutes with every rounding of the update)
         if (staged) {                                  // (uniform) the region guessed above; this wave's reads of the other direction are done
             wave_lds_order();
             stage_write(pre, lds, segs, inv_segs, tasks, 0, lane);
@@ -1100,12 +1117,12 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         // the threshold test on the numerator (correctly rounded division is monotone; the host found the matching bound), the
         // division itself only where the quotient is an output
         const float eigNum = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
-        if (flags & 8) err = eigNum / (float)(2 * w * h);
+        if (flags & 8) err = eigNum;               // (the numerator: divided once, behind the level loop)
         if (eigNum < a.min_eig_num || Dd < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
-        Dd = 1.f / Dd;
+        Dd = rcp_exact_normal(Dd);
         const float Dds = Dd * FLT_SCALE;
         // lanes 0-7 of a DPP row own the b1 total (dx = A12 other - A22 own, dy = A12 own - A11 other), lanes 8-15 the b2 total
         const bool hi8 = (l32 & 8) != 0;
@@ -1214,6 +1231,8 @@ __device__ __forceinline__ void lk_one(const LKArgs& a, const VofeLevel* __restr
         }
         lds_order();
     }
+    // OPTFLOW_LK_GET_MIN_EIGENVALS: err holds the numerator of the last level that reached the test; one division here
+    if (flags & 8) err = err / (float)(2 * w * h);
 }
 }  // namespace x2
 
