@@ -58,10 +58,12 @@ LK_PMC = {
     # (lk_track_kernel_x2<2, false, false>: 127 VGPRs, 4 wavefronts per SIMD, the counter-free instance.  History of this launch
     # shape: round 2's 150-VGPR kernel 590.7e6 instructions in 20955989.7 / 8 cycles = 0.220 per cycle per SIMD
     # (profiles/r02_pmc_inst_v5.txt); the 4-wave kernel 579.9e6 in 19008023.7 / 8 = 0.238 (r03_pmc_inst_v2.txt); after the
-    # instruction-count work on the iteration and the level prologue 498.8e6 in 17163872.7 / 8 = 0.227 (r03_pmc_inst_v3.txt))
-    (64, 2000): {"valu_instr": 498761763.0, "cycles": 17163872.7 / 8, "fetch_kb": 1832331.9, "write_kb": 6437.1,
-                 "kernel_source": ("lk.hip", "27f083446f728066"),
-                 "source": "profiles/r03_pmc_inst_v3.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v3.txt, r03_pmc_write_v3.txt"},
+    # instruction-count work on the iteration and the level prologue 498.8e6 in 17163872.7 / 8 = 0.227 (r03_pmc_inst_v3.txt);
+    # with the min-eig quotient behind the level loop and the hand-written reciprocal 492.1e6 in 17007398.0 / 8 = 0.226
+    # (r03_pmc_inst_v4.txt))
+    (64, 2000): {"valu_instr": 492105763.0, "cycles": 17007398.0 / 8, "fetch_kb": 1827692.3, "write_kb": 6475.1,
+                 "kernel_source": ("lk.hip", "f9a996004dca89d4"),
+                 "source": "profiles/r03_pmc_inst_v4.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs), r03_pmc_fetch_v4.txt, r03_pmc_write_v4.txt"},
 }
 # corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
 # instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
