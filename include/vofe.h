@@ -120,15 +120,19 @@ int vofe_profile_begin(vofe_ctx* ctx);
 int vofe_profile_end(vofe_ctx* ctx, int capacity, char* names, float* ms, int* n_out);
 
 /* ---- corner detection --------------------------------------------------------------------------
- * vofe_corner_score replaces cv::cornerMinEigenVal / cv::cornerHarris (blockSize 3, Sobel
- * aperture 3) that cv2.goodFeaturesToTrack runs at reference continuous.py:380-385 and
- * initialization.py:41-42.  d_score is (batch, height, width) f32, contiguous. */
+ * vofe_corner_score replaces cv::cornerMinEigenVal / cv::cornerHarris that cv2.goodFeaturesToTrack
+ * runs at reference continuous.py:380-385 and initialization.py:41-42 (there with cv2's defaults,
+ * blockSize 3 and Sobel aperture 3, which have dedicated kernels).  block_size 1..31 and aperture
+ * (cv2: gradientSize / ksize) 1, 3, 5 or 7 are implemented: VOFE_E_ARG for values cv2 rejects too
+ * (block_size < 1, even or non-positive aperture), VOFE_E_UNSUPPORTED beyond the implemented range.
+ * d_score is (batch, height, width) f32, contiguous. */
 int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
                       int pitch, size_t img_stride, int block_size, int aperture, int harris,
                       double k, float* d_score);
 
 /* Replaces cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
- * useHarrisDetector, k) (reference continuous.py:380-385, initialization.py:41-42).
+ * useHarrisDetector, k[, gradientSize]) (reference continuous.py:380-385, initialization.py:41-42);
+ * block_size / aperture as for vofe_corner_score.
  * d_corners_xy receives min(*h_n_out, capacity) (x,y) f32 pairs, strongest first; *h_n_out (host) the
  * number of corners cv2 would return (0 == cv2 returning None): at most max_corners when that is
  * positive, every accepted corner otherwise -- it exceeds capacity whenever capacity is the smaller.

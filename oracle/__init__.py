@@ -51,6 +51,11 @@ def lib():
         L.vofe_cpu_corner_score.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
         L.vofe_cpu_gftt.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p,
                                     C.c_int, C.c_double, f32p, C.c_int, i32p, C.c_int]
+        L.vofe_cpu_corner_score_ex.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p,
+                                               C.c_int]
+        L.vofe_cpu_corner_score_generic.argtypes = L.vofe_cpu_corner_score_ex.argtypes
+        L.vofe_cpu_gftt_ex.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p,
+                                       C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int, i32p, C.c_int]
         L.vofe_cpu_set_variant.argtypes = [C.c_int] * 6
         L.vofe_cpu_set_simd.argtypes = [C.c_int]
         _LIB = L
@@ -65,7 +70,8 @@ LK_VARIANTS = {
     "f32_lane8_fma": dict(lk_sum=7),
 }
 SCORE_VARIANTS = {
-    "sobel_fma": dict(sobel=1), "sobel_scale_after": dict(sobel=2), "mineig_fma": dict(mineig_fma=1),
+    "sobel_fma": dict(sobel=1), "sobel_scale_after": dict(sobel=2), "sobel_row_taps": dict(sobel=3),
+    "mineig_fma": dict(mineig_fma=1),
     "box_running": dict(box_running=1), "thresh_ipp": dict(thresh_ipp=1),
     "all_fma": dict(sobel=1, mineig_fma=1, box_running=1, thresh_ipp=1),
 }
@@ -202,20 +208,22 @@ def track_keypoints(prev_keypoints, img_prev, img_current, winSize=(21, 21), max
     return nxt.T, st, err
 
 
-def corner_score(img, harris=False, k=0.04, nthreads=1):
+def corner_score(img, harris=False, k=0.04, nthreads=1, blockSize=3, ksize=3, force_generic=False):
+    """cornerMinEigenVal / cornerHarris score map.  blockSize 1..31, ksize (Sobel aperture) 1, 3, 5 or 7; block 3 / aperture 3
+    (what the reference uses) takes the dedicated restatement, everything else the generic one (`force_generic`: also 3 / 3)."""
     img = _img(img)
     h, w = img.shape
     out = np.empty((h, w), np.float32)
-    rc = lib().vofe_cpu_corner_score(_p(img, C.c_uint8), h, w, w, int(bool(harris)), float(k), _p(out, C.c_float),
-                                     int(nthreads))
-    assert rc == 0
+    fn = lib().vofe_cpu_corner_score_generic if force_generic else lib().vofe_cpu_corner_score_ex
+    rc = fn(_p(img, C.c_uint8), h, w, w, int(blockSize), int(ksize), int(bool(harris)), float(k), _p(out, C.c_float),
+            int(nthreads))
+    if rc:
+        raise ValueError("vofe_cpu_corner_score: bad arguments (rc=%d)" % rc)
     return out
 
 
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
-                        useHarrisDetector=False, k=0.04, nthreads=1):
-    if blockSize != 3:
-        raise ValueError("oracle restates blockSize=3 only (the reference never passes another)")
+                        useHarrisDetector=False, k=0.04, nthreads=1, gradientSize=3):
     img = _img(image)
     h, w = img.shape
     cap = maxCorners if maxCorners > 0 else h * w
@@ -226,10 +234,10 @@ def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
         m = np.ascontiguousarray(np.asarray(mask, np.uint8))
         if m.shape != img.shape:
             raise ValueError("mask must match the image size")
-    rc = lib().vofe_cpu_gftt(_p(img, C.c_uint8), h, w, w, int(maxCorners), float(qualityLevel),
-                             float(minDistance), _p(m, C.c_uint8) if m is not None else None,
-                             int(bool(useHarrisDetector)), float(k), _p(out, C.c_float), cap, C.byref(n),
-                             int(nthreads))
+    rc = lib().vofe_cpu_gftt_ex(_p(img, C.c_uint8), h, w, w, int(maxCorners), float(qualityLevel),
+                                float(minDistance), _p(m, C.c_uint8) if m is not None else None,
+                                int(blockSize), int(gradientSize), int(bool(useHarrisDetector)), float(k),
+                                _p(out, C.c_float), cap, C.byref(n), int(nthreads))
     if rc:
         raise ValueError("vofe_cpu_gftt: bad arguments (rc=%d)" % rc)
     if n.value == 0:

@@ -76,10 +76,77 @@ def corner_score(img, harris=False, k=0.04):
     return (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2))
 
 
-def gftt(img, max_corners, quality, min_distance, mask=None, harris=False, k=0.04):
+def sobel_taps(ksize, order):
+    """cv::getSobelKernels for one axis in closed form: binomial smoothing taps (order 0) = [1 1] convolved ksize-1 times;
+    first-derivative taps (order 1) = the binomial of length ksize-1 convolved with [-1 1].  ksize 1 with order 1 -> 3 taps."""
+    if ksize == 1 and order > 0:
+        ksize = 3
+    k = np.array([1], np.int64)
+    for _ in range(ksize - order - 1):
+        k = np.convolve(k, [1, 1])
+    if order:
+        k = np.convolve(k, [-1, 1])
+    return k
+
+
+def corner_score_generic(img, block=3, ksize=3, harris=False, k=0.04):
+    """A.1 for any blockSize / Sobel aperture, same operation order as oracle/vofe_oracle.cpp corner_score_generic, written
+    with whole-array shifts instead of per-pixel loops."""
+    h, w = img.shape
+    scale = 1.0 / (float(1 << (ksize - 1)) * block * 255.0)
+    dt, st = sobel_taps(ksize, 1), sobel_taps(ksize, 0)
+    ld, ls = len(dt), len(st)
+    hd, hs = ld // 2, ls // 2
+    fs = [F32(float(t) * scale) for t in st]
+    fd = [F32(t) for t in dt]
+    hm = max(hd, hs)
+    a = _pad101(img, ((0, 0), (hm, hm)))
+    af, ai = a.astype(F32), a.astype(np.int32)
+
+    def col(j, half):                                   # image column x - half + j for every x
+        return slice(hm - half + j, hm - half + j + w)
+    r = fd[0] * af[:, col(0, hd)]
+    for j in range(1, ld):
+        r = r + fd[j] * af[:, col(j, hd)]
+    if ls == 3:
+        q = fs[1] * af[:, col(1, 1)] + fs[0] * (ai[:, col(0, 1)] + ai[:, col(2, 1)]).astype(F32)
+    else:
+        q = fs[0] * af[:, col(0, hs)]
+        for j in range(1, ls):
+            q = q + fs[j] * af[:, col(j, hs)]
+    rp, qp = _pad101(r, ((hm, hm), (0, 0))), _pad101(q, ((hm, hm), (0, 0)))
+
+    def row(t):
+        return slice(hm + t, hm + t + h)
+    dx = fs[hs] * rp[row(0)]
+    for t in range(1, hs + 1):
+        dx = dx + fs[hs + t] * (rp[row(t)] + rp[row(-t)])
+    dy = np.zeros((h, w), F32)
+    for t in range(1, hd + 1):
+        dy = dy + fd[hd + t] * (qp[row(t)] - qp[row(-t)])
+    an = block // 2
+    out = []
+    for c in (dx * dx, dx * dy, dy * dy):
+        cp = _pad101(c, ((an, block - 1 - an), (an, block - 1 - an))).astype(np.float64)
+        rs = cp[:, 0:w]
+        for i in range(1, block):
+            rs = rs + cp[:, i:i + w]
+        tot = rs[0:h]
+        for j in range(1, block):
+            tot = tot + rs[j:j + h]
+        out.append(tot.astype(F32))
+    c0, c1, c2 = out
+    if not harris:
+        a_, b_, c_ = c0 * F32(0.5), c1, c2 * F32(0.5)
+        return (a_ + c_) - np.sqrt((a_ - c_) * (a_ - c_) + b_ * b_)
+    kf = F32(k)
+    return (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2))
+
+
+def gftt(img, max_corners, quality, min_distance, mask=None, harris=False, k=0.04, block=3, ksize=3):
     """A.2, sequential greedy with a brute-force distance test (no grid: A.2 step 6 shows the grid
     never changes the outcome because cell >= minDistance - 0.5)."""
-    eig = corner_score(img, harris, k)
+    eig = corner_score(img, harris, k) if (block == 3 and ksize == 3) else corner_score_generic(img, block, ksize, harris, k)
     h, w = eig.shape
     sel = eig if mask is None else eig[mask != 0]
     if sel.size == 0:

@@ -53,6 +53,8 @@ struct Variant {
                           //     without/with FMA, b by int32 pair dot products converted to f32 (x86 wheel)
                           // 6/7 eight f32 lanes, 8 px per step, without/with FMA (a 256-bit build)
     int sobel = 0;        // A.1 step 2.  0 canonical | 1 FMA in the smoothing pass | 2 exact integer Sobel, scaled after (IPP-like)
+                          //   | 3 the smoothing ROW pass accumulated tap by tap, left to right (OpenCV's generic RowFilter
+                          //   for 8u -> 32f) instead of the symmetric form
     int mineig_fma = 0;   // A.1 step 5.  sqrt argument as fma(b, b, (a-c)*(a-c))
     int box_running = 0;  // A.1 step 4.  f64 box sums as OpenCV's running row / column sums instead of direct 3+3 sums
     int harris = 0;       // A.1 step 5.  0 canonical f32 k*((a+c)^2) | 1 scalar path with k double | 2 f32 (k*(a+c))*(a+c)
@@ -606,6 +608,11 @@ void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, doubl
                     q0 = s2 * (float)a[x] + s1 * (float)(a[xm] + a[xp]);
                     q2 = s2 * (float)c[x] + s1 * (float)(c[xm] + c[xp]);
                     dy[(size_t)y * w + x] = q2 - q0;
+                } else if (V.sobel == 3) {       // row smoothing tap by tap: (s*I[x-1] + 2s*I[x]) + s*I[x+1]
+                    dx[(size_t)y * w + x] = s2 * r1 + s1 * (r0 + r2);
+                    q0 = (s1 * (float)a[xm] + s2 * (float)a[x]) + s1 * (float)a[xp];
+                    q2 = (s1 * (float)c[xm] + s2 * (float)c[x]) + s1 * (float)c[xp];
+                    dy[(size_t)y * w + x] = q2 - q0;
                 } else if (V.sobel == 1) {       // muladd in the smoothing passes: f0*S0 first, then fma of the outer taps
                     dx[(size_t)y * w + x] = fmaf(r0 + r2, s1, s2 * r1);
                     q0 = fmaf((float)(a[xm] + a[xp]), s1, s2 * (float)a[x]);
@@ -684,13 +691,116 @@ void corner_score(const uint8_t* img, int h, int w, int pitch, int harris, doubl
     });
 }
 
+// ---------------------------------------------------------------- score map, any blockSize / Sobel aperture
+// cv::getSobelKernels (imgproc/src/deriv.cpp) for one axis: integer taps of the binomial smoothing kernel (order 0) or of the
+// first-derivative kernel (order 1).  ksize 1 with order 1 becomes the 3-tap [-1 0 1] as in OpenCV.
+std::vector<int> sobel_taps(int ksize, int order) {
+    if (ksize == 1 && order > 0) ksize = 3;
+    std::vector<int> k(ksize + 1, 0);
+    if (ksize == 1) { k[0] = 1; }
+    else if (ksize == 3) {
+        if (order == 0) { k[0] = 1; k[1] = 2; k[2] = 1; }
+        else { k[0] = -1; k[1] = 0; k[2] = 1; }
+    } else {
+        k[0] = 1;
+        for (int i = 0; i < ksize - order - 1; ++i) {
+            int oldval = k[0];
+            for (int j = 1; j <= ksize; ++j) { int nv = k[j] + k[j - 1]; k[j - 1] = oldval; oldval = nv; }
+        }
+        for (int i = 0; i < order; ++i) {
+            int oldval = -k[0];
+            for (int j = 1; j <= ksize; ++j) { int nv = k[j - 1] - k[j]; k[j - 1] = oldval; oldval = nv; }
+        }
+    }
+    k.resize(ksize);
+    return k;
+}
+
+// cornerEigenValsVecs with any block_size >= 1 and aperture in {1, 3, 5, 7} (OpenCV corner.cpp; SURVEY A.1 generalised).
+// Operation order (what the HIP kernel corner_score_generic follows bit for bit):
+//  - scale = 1 / (2^(aperture-1) * block_size * 255) in double; the SMOOTHING kernel carries it: f[j] = (float)(tap[j] * scale)
+//  - row pass u8 -> f32 (cv::RowFilter): s = k[0]*S[0]; s += k[j]*S[j], tap by tap, left to right; the 3-tap smoothing row
+//    keeps the symmetric form of SURVEY A.1 (f[1]*I[x] + f[0]*(float)(I[x-1] + I[x+1])) so that aperture 3 is the same
+//    arithmetic whatever the block size
+//  - column pass f32 -> f32 (cv::SymmColumnFilter): symmetric s = f[c]*S[0]; s += f[c+k]*(S[k] + S[-k]);
+//    antisymmetric s = 0; s += d[c+k]*(S[k] - S[-k])
+//  - products in f32; box sum of block_size x block_size products in f64: each row left to right, then the rows top to
+//    bottom, anchor block_size / 2, REFLECT_101 on the product maps; one rounding to f32
+void corner_score_generic(const uint8_t* img, int h, int w, int pitch, int block, int aperture, int harris, double k,
+                          float* score, int nthreads) {
+    const Variant V = g_variant;
+    const double scale = 1.0 / ((double)(1 << (aperture - 1)) * block * 255.0);
+    const std::vector<int> dt = sobel_taps(aperture, 1), st = sobel_taps(aperture, 0);
+    const int Ld = (int)dt.size(), Ls = (int)st.size(), hd = Ld / 2, hs = Ls / 2;
+    std::vector<float> fs(Ls), fd(Ld);
+    for (int j = 0; j < Ls; ++j) fs[j] = (float)((double)st[j] * scale);
+    for (int j = 0; j < Ld; ++j) fd[j] = (float)dt[j];
+    std::vector<float> R((size_t)h * w), Q((size_t)h * w), dx((size_t)h * w), dy((size_t)h * w);
+    parallel_for(h, nthreads, [&](int y0, int y1) {
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t* row = img + (size_t)y * pitch;
+            for (int x = 0; x < w; ++x) {
+                float s = fd[0] * (float)row[reflect101(x - hd, w)];
+                for (int j = 1; j < Ld; ++j) s += fd[j] * (float)row[reflect101(x - hd + j, w)];
+                R[(size_t)y * w + x] = s;
+                float q;
+                if (Ls == 3)
+                    q = fs[1] * (float)row[x] + fs[0] * (float)((int)row[reflect101(x - 1, w)] + (int)row[reflect101(x + 1, w)]);
+                else {
+                    q = fs[0] * (float)row[reflect101(x - hs, w)];
+                    for (int j = 1; j < Ls; ++j) q += fs[j] * (float)row[reflect101(x - hs + j, w)];
+                }
+                Q[(size_t)y * w + x] = q;
+            }
+        }
+    });
+    parallel_for(h, nthreads, [&](int y0, int y1) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < w; ++x) {
+                float s = fs[hs] * R[(size_t)y * w + x];
+                for (int t = 1; t <= hs; ++t)
+                    s += fs[hs + t] * (R[(size_t)reflect101(y + t, h) * w + x] + R[(size_t)reflect101(y - t, h) * w + x]);
+                dx[(size_t)y * w + x] = s;
+                float d = 0.f;
+                for (int t = 1; t <= hd; ++t)
+                    d += fd[hd + t] * (Q[(size_t)reflect101(y + t, h) * w + x] - Q[(size_t)reflect101(y - t, h) * w + x]);
+                dy[(size_t)y * w + x] = d;
+            }
+    });
+    const int an = block / 2;
+    parallel_for(h, nthreads, [&](int y0, int y1) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < w; ++x) {
+                double t0 = 0, t1 = 0, t2 = 0;
+                for (int j = 0; j < block; ++j) {
+                    const int sy = reflect101(y - an + j, h);
+                    double a0 = 0, a1 = 0, a2 = 0;
+                    for (int i = 0; i < block; ++i) {
+                        const int sx = reflect101(x - an + i, w);
+                        const float gx = dx[(size_t)sy * w + sx], gy = dy[(size_t)sy * w + sx];
+                        const float c0 = gx * gx, c1 = gx * gy, c2 = gy * gy;
+                        if (i == 0) { a0 = c0; a1 = c1; a2 = c2; }
+                        else { a0 += (double)c0; a1 += (double)c1; a2 += (double)c2; }
+                    }
+                    if (j == 0) { t0 = a0; t1 = a1; t2 = a2; }
+                    else { t0 += a0; t1 += a1; t2 += a2; }
+                }
+                score[(size_t)y * w + x] = score_from_cov((float)t0, (float)t1, (float)t2, harris, k, V);
+            }
+    });
+}
+
+bool score_geometry_ok(int block, int aperture) {
+    return block >= 1 && block <= 31 && (aperture == 1 || aperture == 3 || aperture == 5 || aperture == 7);
+}
+
 }  // namespace
 
 // ================================================================= C ABI
 extern "C" {
 
 int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running, int harris, int thresh_ipp) {
-    if (lk_sum < 0 || lk_sum > 7 || sobel < 0 || sobel > 2 || harris < 0 || harris > 2) return -1;
+    if (lk_sum < 0 || lk_sum > 7 || sobel < 0 || sobel > 3 || harris < 0 || harris > 2) return -1;
     g_variant.lk_sum = lk_sum; g_variant.sobel = sobel; g_variant.mineig_fma = !!mineig_fma;
     g_variant.box_running = !!box_running; g_variant.harris = harris; g_variant.thresh_ipp = !!thresh_ipp;
     return 0;
@@ -792,22 +902,43 @@ int vofe_cpu_track_fb(const uint8_t* prev_img, const uint8_t* next_img, int h, i
     return 0;
 }
 
+int vofe_cpu_corner_score_ex(const uint8_t* img, int h, int w, int pitch, int block_size, int aperture, int harris,
+                             double k, float* score, int nthreads) {
+    if (!img || !score || h <= 0 || w <= 0 || !score_geometry_ok(block_size, aperture)) return -1;
+    if (block_size == 3 && aperture == 3) corner_score(img, h, w, pitch, harris, k, score, nthreads);
+    else corner_score_generic(img, h, w, pitch, block_size, aperture, harris, k, score, nthreads);
+    return 0;
+}
 int vofe_cpu_corner_score(const uint8_t* img, int h, int w, int pitch, int harris, double k,
                           float* score, int nthreads) {
-    if (!img || !score || h <= 0 || w <= 0) return -1;
-    corner_score(img, h, w, pitch, harris, k, score, nthreads);
+    return vofe_cpu_corner_score_ex(img, h, w, pitch, 3, 3, harris, k, score, nthreads);
+}
+/* test aid: the generic path forced for block 3 / aperture 3 too (must reproduce the dedicated path bit for bit) */
+int vofe_cpu_corner_score_generic(const uint8_t* img, int h, int w, int pitch, int block_size, int aperture, int harris,
+                                  double k, float* score, int nthreads) {
+    if (!img || !score || h <= 0 || w <= 0 || !score_geometry_ok(block_size, aperture)) return -1;
+    corner_score_generic(img, h, w, pitch, block_size, aperture, harris, k, score, nthreads);
     return 0;
 }
 
 int vofe_cpu_gftt(const uint8_t* img, int h, int w, int pitch, int max_corners, double quality,
                   double min_distance, const uint8_t* mask, int harris, double k,
                   float* corners_xy, int capacity, int* n_out, int nthreads) {
+    return vofe_cpu_gftt_ex(img, h, w, pitch, max_corners, quality, min_distance, mask, 3, 3, harris, k, corners_xy, capacity,
+                            n_out, nthreads);
+}
+
+int vofe_cpu_gftt_ex(const uint8_t* img, int h, int w, int pitch, int max_corners, double quality,
+                     double min_distance, const uint8_t* mask, int block_size, int aperture, int harris, double k,
+                     float* corners_xy, int capacity, int* n_out, int nthreads) {
     if (!n_out) return -1;
     *n_out = 0;
     if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0) return -2;     // SURVEY A.2 asserts
+    if (!score_geometry_ok(block_size, aperture)) return -2;
     if (!img || h <= 0 || w <= 0) return 0;                                       // empty image -> None
     std::vector<float> eig((size_t)h * w);
-    corner_score(img, h, w, pitch, harris, k, eig.data(), nthreads);
+    if (block_size == 3 && aperture == 3) corner_score(img, h, w, pitch, harris, k, eig.data(), nthreads);
+    else corner_score_generic(img, h, w, pitch, block_size, aperture, harris, k, eig.data(), nthreads);
     // 1. global max (within mask)
     bool any = false;
     float maxv = 0.f;

@@ -27,7 +27,8 @@ extern "C" {
  * how far the plausible cv2 arithmetics are from the canonical one (tests/test_variants_cpu.py).
  *   lk_sum      A.5 steps 4/6: 0 exact int64 | 1 f32 raster | 2,3 4 lanes (w/o, with FMA) | 4,5 128-bit universal
  *               intrinsics loop (8 px per step, pair dot products for b) | 6,7 8 lanes (w/o, with FMA)
- *   sobel       A.1 step 2: 0 canonical | 1 FMA in the smoothing passes | 2 integer Sobel scaled afterwards
+ *   sobel       A.1 step 2: 0 canonical | 1 FMA in the smoothing passes | 2 integer Sobel scaled afterwards | 3 smoothing
+ *               row pass accumulated tap by tap (OpenCV's generic 8u -> 32f RowFilter)
  *   mineig_fma  A.1 step 5;  box_running  A.1 step 4 (running f64 sums);  harris  0 | 1 scalar double-k | 2 vector f32
  *   thresh_ipp  A.2 step 2: v < thr + FLT_EPSILON -> 0 */
 int vofe_cpu_set_variant(int lk_sum, int sobel, int mineig_fma, int box_running, int harris, int thresh_ipp);
@@ -68,12 +69,26 @@ int vofe_cpu_track_fb(const uint8_t* prev_img, const uint8_t* next_img, int h, i
 int vofe_cpu_corner_score(const uint8_t* img, int h, int w, int pitch, int harris, double k,
                           float* score, int nthreads);
 
+/* The same for any blockSize in 1..31 and Sobel aperture (gradientSize) in {1, 3, 5, 7}: OpenCV's getSobelKernels taps, scale
+ * 1 / (2^(aperture-1) * blockSize * 255) on the smoothing kernel, row pass tap by tap, symmetric / antisymmetric column
+ * pass, blockSize x blockSize box sum in f64 with anchor blockSize / 2 (operation order stated at corner_score_generic in the
+ * .cpp).  Block 3 / aperture 3 takes the dedicated path above; vofe_cpu_corner_score_generic forces the generic one (tests: both
+ * must agree bit for bit). */
+int vofe_cpu_corner_score_ex(const uint8_t* img, int h, int w, int pitch, int block_size, int aperture, int harris,
+                             double k, float* score, int nthreads);
+int vofe_cpu_corner_score_generic(const uint8_t* img, int h, int w, int pitch, int block_size, int aperture, int harris,
+                                  double k, float* score, int nthreads);
+
 /* cv2.goodFeaturesToTrack.  corners_xy holds up to max_corners (x,y) pairs when
  * max_corners > 0, else up to h*w pairs.  *n_out = number of corners (0 == cv2 returning None).
  * mask may be NULL. */
 int vofe_cpu_gftt(const uint8_t* img, int h, int w, int pitch, int max_corners, double quality,
                   double min_distance, const uint8_t* mask, int harris, double k,
                   float* corners_xy, int capacity, int* n_out, int nthreads);
+/* ... with blockSize / gradientSize as cv2.goodFeaturesToTrack takes them (same ranges as vofe_cpu_corner_score_ex). */
+int vofe_cpu_gftt_ex(const uint8_t* img, int h, int w, int pitch, int max_corners, double quality,
+                     double min_distance, const uint8_t* mask, int block_size, int aperture, int harris, double k,
+                     float* corners_xy, int capacity, int* n_out, int nthreads);
 
 #ifdef __cplusplus
 }

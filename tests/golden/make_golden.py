@@ -16,10 +16,17 @@ corners = oracle.goodFeaturesToTrack(a, 32, 0.01, 5)
 pts = synthetic.pad_points(corners, 32, 48, 64, 123)
 n, s, e = oracle.calcOpticalFlowPyrLK(a, b, pts, None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
 t, fs, fe = oracle.track_keypoints(pts.T, a, b, (11, 11), 2)
+# cv2's optional blockSize / gradientSize (the reference passes neither): a few geometries of the generic score path
+GEOM = [(5, 3), (3, 5), (7, 7), (2, 1)]
+geom = {}
+for bs, ks in GEOM:
+    geom["score_b%d_k%d" % (bs, ks)] = oracle.corner_score(a, blockSize=bs, ksize=ks)
+    geom["harris_b%d_k%d" % (bs, ks)] = oracle.corner_score(a, True, blockSize=bs, ksize=ks)
+    geom["corners_b%d_k%d" % (bs, ks)] = oracle.goodFeaturesToTrack(a, 32, 0.01, 5, blockSize=bs, gradientSize=ks)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "frontend_small.npz"),
                     img0=a, img1=b, pyr1=oracle.pyr_down(a), scharr0=oracle.scharr(a), score=oracle.corner_score(a),
                     harris=oracle.corner_score(a, True), corners=corners, pts=pts, lk_next=n, lk_status=s, lk_err=e,
-                    fb_next=t, fb_status=fs, fb_err=fe)
+                    fb_next=t, fb_status=fs, fb_err=fe, **geom)
 print("written", len(pts), "points,", corners.shape[0], "corners")
 
 # The alternative arithmetics (oracle.variant, SURVEY Appendix A warning points) on a second small case: what each of them

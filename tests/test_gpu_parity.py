@@ -38,6 +38,10 @@ def test_hip_path_against_the_committed_golden_fixture(fe):
     assert np.array_equal(fe.corner_score(a), z["score"])
     assert np.array_equal(fe.corner_score(a, True), z["harris"])
     assert np.array_equal(fe.goodFeaturesToTrack(a, 32, 0.01, 5), z["corners"])
+    for bs, ks in ((5, 3), (3, 5), (7, 7), (2, 1)):                   # cv2's optional blockSize / gradientSize
+        assert np.array_equal(fe.corner_score(a, False, 0.04, bs, ks), z["score_b%d_k%d" % (bs, ks)]), (bs, ks)
+        assert np.array_equal(fe.corner_score(a, True, 0.04, bs, ks), z["harris_b%d_k%d" % (bs, ks)]), (bs, ks)
+        assert np.array_equal(fe.goodFeaturesToTrack(a, 32, 0.01, 5, blockSize=bs, gradientSize=ks), z["corners_b%d_k%d" % (bs, ks)])
     n, s, e = fe.calcOpticalFlowPyrLK(a, b, pts, None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
     assert np.array_equal(s, z["lk_status"])
     ok = s.ravel() == 1
@@ -445,6 +449,89 @@ def test_corner_score_kernel_paths_and_edges(fe, knob, path):
         mask = np.zeros((129, 1030), np.uint8); mask[r0:r1, c0:c1] = 1
         assert np.array_equal(fe.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask),
                               oracle.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask))
+
+
+SCORE_GEOM = [(1, 3), (2, 3), (3, 1), (3, 5), (5, 3), (5, 5), (7, 7), (4, 7), (15, 5), (31, 1), (31, 7), (16, 3)]
+
+
+@pytest.mark.parametrize("block,ksize", SCORE_GEOM)
+def test_corner_score_any_block_size_and_aperture_bit_exact(fe, block, ksize):
+    """cv2.goodFeaturesToTrack's optional blockSize / gradientSize (cornerMinEigenVal / cornerHarris with any block and a
+    Sobel aperture of 1, 3, 5 or 7): the run-time-geometry kernel against the oracle's generic restatement, incl. frames
+    smaller than the box or the Sobel kernel (REFLECT_101 bounces more than once), one-pixel frames, tile edges."""
+    rng = np.random.default_rng(block * 10 + ksize)
+    for (h, w) in ((97, 131), (1, 1), (1, 50), (40, 2), (3, 3), (16, 64), (17, 65), (15, 33), (33, 16), (20, 17), (200, 333)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8) if h * w < 3000 else _seq(h, w, h + w, 1)[0]
+        for harris in (False, True):
+            got = fe.corner_score(a, harris, 0.04, block, ksize)
+            ref = oracle.corner_score(a, harris, 0.04, blockSize=block, ksize=ksize)
+            assert np.array_equal(got, ref), (h, w, harris)
+    big = _seq(376, 1241, 0, 1)[0]
+    assert np.array_equal(fe.corner_score(big, False, 0.04, block, ksize),
+                          oracle.corner_score(big, False, 0.04, nthreads=8, blockSize=block, ksize=ksize))
+
+
+def test_generic_score_kernel_forced_for_the_default_geometry(fe, knob):
+    """VOFE_CORNER_SCORE=generic sends block 3 / aperture 3 through the run-time-geometry kernel: same maps and corners as the
+    dedicated kernels and the dedicated restatement, bit for bit."""
+    knob("VOFE_CORNER_SCORE", "generic")
+    rng = np.random.default_rng(5)
+    for (h, w) in ((2, 8), (3, 9), (17, 255), (33, 257), (129, 1030), (376, 1241)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8) if h < 100 else _seq(h, w, 6, 1)[0]
+        for harris in (False, True):
+            assert np.array_equal(fe.corner_score(a, harris, 0.04), oracle.corner_score(a, harris, 0.04, nthreads=8)), (h, w, harris)
+    a = _seq(376, 1241, 0, 1)[0]
+    assert np.array_equal(fe.goodFeaturesToTrack(a, 1000, 0.01, 10), oracle.goodFeaturesToTrack(a, 1000, 0.01, 10, nthreads=8))
+
+
+@pytest.mark.parametrize("block,ksize", [(5, 3), (7, 3), (3, 5), (7, 7), (2, 1), (11, 5)])
+def test_gftt_with_block_size_and_gradient_size(fe, block, ksize):
+    """The detector with cv2's optional arguments (OpenCV's own LK example passes blockSize=7): identical corner lists, also
+    with a mask, Harris, through the batched and the no-allocation entry points."""
+    import ctypes as C
+    import torch
+    from visual_odometry_amd import _lib
+    for (h, w, seed, maxc, q, md) in ((376, 1241, 0, 1000, 0.01, 10), (480, 640, 3, 500, 0.01, 7), (200, 300, 8, 0, 0.05, 5.5)):
+        a = _seq(h, w, seed, 1)[0]
+        ref = oracle.goodFeaturesToTrack(a, maxc, q, md, blockSize=block, gradientSize=ksize, nthreads=8)
+        got = fe.goodFeaturesToTrack(a, maxc, q, md, blockSize=block, gradientSize=ksize)
+        assert ref is not None and np.array_equal(got, ref), (h, w)
+    a = _seq(200, 300, 8, 1)[0]
+    mask = np.zeros_like(a); mask[50:150, 100:250] = 255
+    for harris in (False, True):
+        ref = oracle.goodFeaturesToTrack(a, 200, 0.01, 8, mask=mask, blockSize=block, useHarrisDetector=harris, gradientSize=ksize)
+        got = fe.goodFeaturesToTrack(a, 200, 0.01, 8, mask=mask, blockSize=block, useHarrisDetector=harris, gradientSize=ksize)
+        assert np.array_equal(got, ref), harris
+    # raw C ABI: batched and no-allocation entry points with the same geometry
+    L = fe.L
+    frames = np.stack(_seq(120, 160, 21, 3))
+    d = torch.from_numpy(frames).cuda()
+    out = torch.empty((3, 100, 2), dtype=torch.float32, device="cuda")
+    cnt = (C.c_int * 3)()
+    _lib.check(L.vofe_gftt_batch(fe.ctx, d.data_ptr(), 3, 120, 160, 160, 120 * 160, 100, 0.01, 6.0, block, ksize, 0, 0.04,
+                                 out.data_ptr(), 100, cnt))
+    fe.synchronize()
+    for i in range(3):
+        ref = oracle.goodFeaturesToTrack(frames[i], 100, 0.01, 6.0, blockSize=block, gradientSize=ksize)
+        assert cnt[i] == ref.shape[0] and np.array_equal(out[i, :cnt[i]].cpu().numpy(), ref.reshape(-1, 2)), i
+    one = C.c_int(0)
+    o1 = torch.empty((100, 2), dtype=torch.float32, device="cuda")
+    _lib.check(L.vofe_gftt_noalloc(fe.ctx, d.data_ptr(), 120, 160, 160, 100, 0.01, 6.0, None, block, ksize, 0, 0.04,
+                                   o1.data_ptr(), 100, C.byref(one)))
+    ref = oracle.goodFeaturesToTrack(frames[0], 100, 0.01, 6.0, blockSize=block, gradientSize=ksize)
+    assert one.value == ref.shape[0] and np.array_equal(o1[:one.value].cpu().numpy(), ref.reshape(-1, 2))
+
+
+def test_block_size_and_gradient_size_argument_errors(fe):
+    """cv2 raises for blockSize < 1 and for an even aperture; apertures above 7 and blocks above 31 are refused here with a
+    message that says so (cv2 would run them)."""
+    from visual_odometry_amd import error
+    a = _seq(64, 64, 1, 1)[0]
+    for kw in (dict(blockSize=0), dict(blockSize=-3), dict(gradientSize=4), dict(gradientSize=0), dict(gradientSize=9), dict(blockSize=32)):
+        with pytest.raises(error):
+            fe.goodFeaturesToTrack(a, 10, 0.01, 5, **kw)
+    with pytest.raises(error):
+        fe.corner_score(a, False, 0.04, 3, 2)
 
 
 @pytest.mark.parametrize("h,w,seed,maxc,q,md", [(376, 1241, 0, 1000, 0.01, 10), (376, 1241, 0, 2000, 0.01, 7),
@@ -1587,11 +1674,14 @@ def test_randomised_gftt_sweep(fe):
         mask = None
         if case % 3 == 0:
             mask = (rng.random((h, w)) > 0.4).astype(np.uint8)
-        got = fe.goodFeaturesToTrack(a, maxc, q, md, mask=mask, useHarrisDetector=harris, k=0.04)
-        ref = oracle.goodFeaturesToTrack(a, maxc, q, md, mask=mask, useHarrisDetector=harris, k=0.04)
-        assert (got is None) == (ref is None), (case, h, w, q, md, maxc)
+        bs, ks = 3, 3
+        if case % 4 == 1:                                             # cv2's optional blockSize / gradientSize
+            bs, ks = int(rng.integers(1, 12)), int(rng.choice([1, 3, 5, 7]))
+        got = fe.goodFeaturesToTrack(a, maxc, q, md, mask=mask, blockSize=bs, useHarrisDetector=harris, k=0.04, gradientSize=ks)
+        ref = oracle.goodFeaturesToTrack(a, maxc, q, md, mask=mask, blockSize=bs, useHarrisDetector=harris, k=0.04, gradientSize=ks)
+        assert (got is None) == (ref is None), (case, h, w, q, md, maxc, bs, ks)
         if ref is not None:
-            assert np.array_equal(got, ref), (case, h, w, q, md, maxc, harris)
+            assert np.array_equal(got, ref), (case, h, w, q, md, maxc, harris, bs, ks)
 
 
 def test_randomised_score_sweep(fe, knob):

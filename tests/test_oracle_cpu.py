@@ -225,6 +225,10 @@ def test_golden_fixtures():
     assert np.array_equal(oracle.corner_score(a, True), z["harris"])
     c = oracle.goodFeaturesToTrack(a, 32, 0.01, 5)
     assert np.array_equal(c, z["corners"])
+    for bs, ks in ((5, 3), (3, 5), (7, 7), (2, 1)):
+        assert np.array_equal(oracle.corner_score(a, blockSize=bs, ksize=ks), z["score_b%d_k%d" % (bs, ks)])
+        assert np.array_equal(oracle.corner_score(a, True, blockSize=bs, ksize=ks), z["harris_b%d_k%d" % (bs, ks)])
+        assert np.array_equal(oracle.goodFeaturesToTrack(a, 32, 0.01, 5, blockSize=bs, gradientSize=ks), z["corners_b%d_k%d" % (bs, ks)])
     n, s, e = oracle.calcOpticalFlowPyrLK(a, b, z["pts"], None, (11, 11), 2, (3, 30, 0.01), 0, 1e-4)
     assert np.array_equal(n, z["lk_next"]) and np.array_equal(s, z["lk_status"]) and np.array_equal(e, z["lk_err"])
     t, s, e = oracle.track_keypoints(z["pts"].T, a, b, (11, 11), 2)
@@ -380,6 +384,73 @@ def test_score_map_pinned_by_scipy_ndimage(harris):
     got = oracle.corner_score(img, harris=harris).astype(np.float64)
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 2e-6 * scale + 1e-12
+
+
+# ------------------------------------------------------------------ any blockSize / gradientSize (cv2's optional arguments)
+GEOM = [(1, 3), (2, 3), (3, 1), (3, 5), (5, 3), (5, 5), (7, 7), (4, 7), (15, 5), (31, 1)]
+
+
+def test_sobel_taps_are_opencvs_kernels():
+    """cv::getSobelKernels' published kernels (its documentation and the classic Sobel tables)."""
+    assert list(T.sobel_taps(1, 0)) == [1] and list(T.sobel_taps(1, 1)) == [-1, 0, 1]
+    assert list(T.sobel_taps(3, 0)) == [1, 2, 1] and list(T.sobel_taps(3, 1)) == [-1, 0, 1]
+    assert list(T.sobel_taps(5, 0)) == [1, 4, 6, 4, 1] and list(T.sobel_taps(5, 1)) == [-1, -2, 0, 2, 1]
+    assert list(T.sobel_taps(7, 0)) == [1, 6, 15, 20, 15, 6, 1] and list(T.sobel_taps(7, 1)) == [-1, -4, -5, 0, 5, 4, 1]
+
+
+@pytest.mark.parametrize("harris", [False, True])
+def test_generic_score_path_reproduces_the_dedicated_one_for_block3_aperture3(harris):
+    for h, w, seed in [(57, 83, 1), (3, 3, 7), (5, 40, 2), (1, 9, 4), (120, 160, 5)]:
+        a = synthetic.sequence(h, w, seed, 1)[0]
+        assert np.array_equal(oracle.corner_score(a, harris, force_generic=True), oracle.corner_score(a, harris))
+        assert np.array_equal(T.corner_score_generic(a, 3, 3, harris), T.corner_score(a, harris))
+
+
+@pytest.mark.parametrize("block,ksize", GEOM)
+@pytest.mark.parametrize("harris", [False, True])
+def test_generic_score_map_matches_twin(block, ksize, harris):
+    """C++ loops vs whole-array numpy, bit for bit, incl. images smaller than the box / the Sobel kernel (REFLECT_101 bounces
+    more than once there, as cv::borderInterpolate does)."""
+    for h, w, seed in [(57, 83, 1), (40, 41, 9), (3, 3, 7), (5, 40, 2), (1, 1, 0), (2, 7, 3), (9, 2, 3)]:
+        a = np.random.default_rng(seed).integers(0, 256, (h, w)).astype(np.uint8) if h * w < 50 else synthetic.sequence(h, w, seed, 1)[0]
+        got = oracle.corner_score(a, harris, blockSize=block, ksize=ksize)
+        assert np.array_equal(got, T.corner_score_generic(a, block, ksize, harris)), (h, w)
+        assert np.array_equal(got, oracle.corner_score(a, harris, blockSize=block, ksize=ksize, nthreads=4))
+
+
+@pytest.mark.parametrize("block,ksize", [(5, 3), (3, 5), (7, 7), (2, 1), (9, 5)])
+@pytest.mark.parametrize("harris", [False, True])
+def test_generic_score_map_pinned_by_scipy_ndimage(block, ksize, harris):
+    """The published definition (Sobel taps of the aperture, 1 / (2^(aperture-1) * blockSize * 255), blockSize x blockSize
+    unnormalised box sum anchored at blockSize / 2) evaluated by scipy.ndimage in float64."""
+    from scipy import ndimage
+    img = _texture(120, 160, 5)
+    a = img.astype(np.float64)
+    sm, df = T.sobel_taps(ksize, 0).astype(np.float64), T.sobel_taps(ksize, 1).astype(np.float64)
+    scale = 1.0 / ((1 << (ksize - 1)) * block * 255.0)
+    dx = ndimage.correlate1d(ndimage.correlate1d(a, df, axis=1, mode="mirror"), sm, axis=0, mode="mirror") * scale
+    dy = ndimage.correlate1d(ndimage.correlate1d(a, sm, axis=1, mode="mirror"), df, axis=0, mode="mirror") * scale
+    # scipy centres an even-length kernel at n // 2 as well: origin 0 is OpenCV's anchor blockSize / 2
+    box = lambda m: ndimage.correlate1d(ndimage.correlate1d(m, np.ones(block), axis=1, mode="mirror"), np.ones(block), axis=0, mode="mirror")
+    xx, xy, yy = box(dx * dx), box(dx * dy), box(dy * dy)
+    if harris:
+        ref = xx * yy - xy * xy - 0.04 * (xx + yy) ** 2
+    else:
+        ref = (xx * 0.5 + yy * 0.5) - np.sqrt((xx * 0.5 - yy * 0.5) ** 2 + xy * xy)
+    got = oracle.corner_score(img, harris=harris, blockSize=block, ksize=ksize).astype(np.float64)
+    assert np.abs(got - ref).max() <= 4e-6 * np.abs(ref).max() + 1e-12
+
+
+@pytest.mark.parametrize("block,ksize", [(5, 3), (7, 5), (2, 1), (3, 7)])
+def test_gftt_with_block_and_gradient_size_matches_twin(block, ksize):
+    a = synthetic.sequence(96, 130, 5, 1)[0]
+    for maxc, q, md in [(50, 0.01, 7), (0, 0.05, 3)]:
+        got = oracle.goodFeaturesToTrack(a, maxc, q, md, blockSize=block, gradientSize=ksize)
+        assert got is not None and np.array_equal(got, T.gftt(a, maxc, q, md, block=block, ksize=ksize))
+    with pytest.raises(ValueError):
+        oracle.goodFeaturesToTrack(a, 10, 0.01, 5, blockSize=0)
+    with pytest.raises(ValueError):
+        oracle.goodFeaturesToTrack(a, 10, 0.01, 5, gradientSize=4)
 
 
 def test_gftt_candidate_rule_pinned_by_scipy_ndimage():

@@ -36,6 +36,7 @@ void vofe_read_knobs(VofeKnobs* k) {
     if (const char* v = getenv("VOFE_PYRAMID")) k->pyramid = (v[0] == 'f' || v[0] == 'l') ? v[0] : 0;
     k->pad_copy_generic = env_is("VOFE_PAD_COPY", 'g');
     k->score_tile = env_is("VOFE_CORNER_SCORE", 't');
+    k->score_generic = env_is("VOFE_CORNER_SCORE", 'g');
     k->score_rs = env_int("VOFE_SCORE_RS", 0);
     k->nms_rows = env_int("VOFE_NMS_ROWS", 0);
     k->pyr_borders_separate = env_is("VOFE_PYR_BORDERS", 's');
@@ -365,8 +366,14 @@ int vofe_lk_set_counters(vofe_ctx* ctx, unsigned long long* d_counters) {
 static int corner_args(const char* who, vofe_ctx* ctx, const uint8_t* d_img, int h, int w, int pitch, int block_size, int aperture) {
     if (!ctx || !d_img) { vofe_set_error("%s: NULL argument", who); return VOFE_E_ARG; }
     if (h <= 0 || w <= 0 || pitch < w) { vofe_set_error("%s: bad image geometry %dx%d pitch %d", who, w, h, pitch); return VOFE_E_ARG; }
-    if (block_size != 3 || aperture != 3) {
-        vofe_set_error("%s: only blockSize=3, gradientSize=3 are implemented (the reference passes neither: continuous.py:380-385)", who);
+    // cv2 takes any blockSize >= 1 and an odd Sobel aperture up to 31 (its documentation names 1, 3, 5, 7); here: block 1..31,
+    // aperture 1, 3, 5 or 7 (the reference passes neither, continuous.py:380-385: block 3 / aperture 3 has dedicated kernels)
+    if (block_size < 1 || aperture < 1 || aperture % 2 == 0) {
+        vofe_set_error("%s: blockSize %d / gradientSize %d: need blockSize >= 1 and an odd gradientSize >= 1", who, block_size, aperture);
+        return VOFE_E_ARG;
+    }
+    if (block_size > 31 || aperture > 7) {
+        vofe_set_error("%s: blockSize %d / gradientSize %d beyond what is implemented (blockSize <= 31; gradientSize 1, 3, 5, 7)", who, block_size, aperture);
         return VOFE_E_UNSUPPORTED;
     }
     return VOFE_OK;
@@ -379,7 +386,8 @@ int vofe_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height
     if (rc) return rc;
     if (!d_score || batch <= 0) { vofe_set_error("vofe_corner_score: NULL score buffer or batch <= 0"); return VOFE_E_ARG; }
     VOFE_BIND(ctx);
-    return vofe_launch_corner_score(ctx, d_img, batch, height, width, pitch, img_stride, harris, (float)k, d_score, nullptr, nullptr);
+    return vofe_launch_corner_score(ctx, d_img, batch, height, width, pitch, img_stride, harris, (float)k, d_score, nullptr, nullptr,
+                                    block_size, aperture);
 }
 
 int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
@@ -397,7 +405,7 @@ int vofe_gftt(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pi
     if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt: bad output buffer"); return VOFE_E_ARG; }
     VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
-                          d_corners_xy, capacity, h_n_out);
+                          d_corners_xy, capacity, h_n_out, nullptr, false, block_size, aperture);
 }
 
 int vofe_gftt_noalloc(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
@@ -415,7 +423,7 @@ int vofe_gftt_noalloc(vofe_ctx* ctx, const uint8_t* d_img, int height, int width
     if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt_noalloc: bad output buffer"); return VOFE_E_ARG; }
     VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
-                          d_corners_xy, capacity, h_n_out, nullptr, true);
+                          d_corners_xy, capacity, h_n_out, nullptr, true, block_size, aperture);
 }
 
 int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, int pitch,
@@ -433,7 +441,7 @@ int vofe_gftt_host(vofe_ctx* ctx, const uint8_t* d_img, int height, int width, i
     if (capacity <= 0 || !d_corners_xy) { vofe_set_error("vofe_gftt_host: bad output buffer"); return VOFE_E_ARG; }
     VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, 1, height, width, pitch, 0, max_corners, quality, min_distance, d_mask, harris, k,
-                          d_corners_xy, capacity, h_n_out, h_corners_xy);
+                          d_corners_xy, capacity, h_n_out, h_corners_xy, false, block_size, aperture);
 }
 
 int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, int width,
@@ -451,7 +459,7 @@ int vofe_gftt_batch(vofe_ctx* ctx, const uint8_t* d_img, int batch, int height, 
     if (capacity < 0 || (capacity > 0 && !d_corners_xy)) { vofe_set_error("vofe_gftt_batch: bad output buffer"); return VOFE_E_ARG; }
     VOFE_BIND(ctx);
     return vofe_gftt_impl(ctx, d_img, batch, height, width, pitch, img_stride, max_corners, quality, min_distance, nullptr,
-                          harris, k, d_corners_xy, capacity, h_n_out);
+                          harris, k, d_corners_xy, capacity, h_n_out, nullptr, false, block_size, aperture);
 }
 
 int vofe_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,

@@ -155,6 +155,137 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// score map for any blockSize (1..31) / Sobel aperture (1, 3, 5, 7): cv2.goodFeaturesToTrack(..., blockSize, gradientSize)
+// and cornerMinEigenVal / cornerHarris with those arguments (the reference passes neither, continuous.py:380-385, so block 3 /
+// aperture 3 keeps its dedicated kernels).  Same structure as corner_score_f32, sizes at run time: image tile with the Sobel
+// halo (REFLECT_101 at load), separable Sobel as OpenCV's filter engine runs it (row pass u8 -> f32 tap by tap, then the
+// symmetric / antisymmetric column pass), products, f64 row sums of blockSize products, f64 column sums of blockSize row sums
+// (anchor blockSize / 2, REFLECT_101 on the product maps: indices are reflected when the sums read, products exist only at
+// image positions).  Operation order = oracle/vofe_oracle.cpp corner_score_generic, bit for bit.
+struct ScoreGeom {
+    int bs, an;                  // box size and anchor
+    int ld, hd, ls, hs, hm;      // derivative / smoothing tap counts, their half widths, image halo = max(hd, hs)
+    int tx, ty;                  // outputs per block
+    float fd[8], fs[8];          // derivative taps (small integers), smoothing taps times the scale
+};
+__host__ __device__ inline size_t score_generic_lds(const ScoreGeom& g) {
+    const size_t PW = g.tx + g.bs - 1, PH = g.ty + g.bs - 1, IW = PW + 2 * g.hm, IH = PH + 2 * g.hm;
+    const size_t rq = 8 * IH * PW, hsum = 24 * PH * (size_t)g.tx;
+    return (rq > hsum ? rq : hsum) + 12 * PH * PW + ((IH * IW + 15) & ~(size_t)15);
+}
+__global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __restrict__ img, int h, int w, int pitch,
+                                                            size_t img_stride, ScoreGeom g, int harris, float kf,
+                                                            float* __restrict__ score, GfttHdr* __restrict__ hdr,
+                                                            const uint8_t* __restrict__ mask) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float sfd[8], sfs[8];
+    __shared__ unsigned sMax;
+    const int PW = g.tx + g.bs - 1, PH = g.ty + g.bs - 1, IW = PW + 2 * g.hm, IH = PH + 2 * g.hm;
+    const size_t rq = 8 * (size_t)IH * PW, hsum = 24 * (size_t)PH * g.tx;
+    // [ R | Q ] (row-pass outputs) share their space with the f64 row sums H[3], which are written after the column pass
+    float* sR = reinterpret_cast<float*>(smem);
+    float* sQ = sR + IH * PW;
+    double* sH = reinterpret_cast<double*>(smem);
+    float* sC = reinterpret_cast<float*>(smem + (rq > hsum ? rq : hsum));
+    uint8_t* sI = reinterpret_cast<uint8_t*>(sC + 3 * PH * PW);
+    const int x0 = blockIdx.x * g.tx, y0 = blockIdx.y * g.ty;
+    const int px0 = x0 - g.an, py0 = y0 - g.an;
+    const uint8_t* im = img + (size_t)blockIdx.z * img_stride;
+    const int tid = threadIdx.x;
+    if (tid == 0) sMax = 0;
+    if (tid < 8) { sfd[tid] = g.fd[tid]; sfs[tid] = g.fs[tid]; }
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int j = e / IW, i = e - j * IW;
+        const int sx = vofe_reflect101(px0 - g.hm + i, w), sy = vofe_reflect101(py0 - g.hm + j, h);
+        sI[e] = im[(size_t)sy * pitch + sx];
+    }
+    __syncthreads();
+    // row pass at every tile row (rows beyond the image are reflected copies, so their row-pass values are the reflected
+    // rows' values), at image columns only
+    for (int e = tid; e < IH * PW; e += 256) {
+        const int j = e / PW, i = e - j * PW;
+        const int cx = px0 + i;
+        if (cx < 0 || cx >= w) continue;
+        const uint8_t* p = sI + j * IW + i + g.hm;
+        float r = sfd[0] * (float)p[-g.hd];
+        for (int t = 1; t < g.ld; ++t) r += sfd[t] * (float)p[t - g.hd];
+        float q;
+        if (g.ls == 3) q = sfs[1] * (float)p[0] + sfs[0] * (float)((int)p[-1] + (int)p[1]);
+        else {
+            q = sfs[0] * (float)p[-g.hs];
+            for (int t = 1; t < g.ls; ++t) q += sfs[t] * (float)p[t - g.hs];
+        }
+        sR[e] = r; sQ[e] = q;
+    }
+    __syncthreads();
+    // column pass and products at image positions of the product region
+    float pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
+    for (int e0 = 0; e0 < PH * PW; e0 += 256) {
+        const int e = e0 + tid;
+        bool have = false;
+        if (e < PH * PW) {
+            const int j = e / PW, i = e - j * PW;
+            const int cx = px0 + i, cy = py0 + j;
+            if (cx >= 0 && cx < w && cy >= 0 && cy < h) {
+                const float* r = sR + (j + g.hm) * PW + i;
+                const float* q = sQ + (j + g.hm) * PW + i;
+                float dx = sfs[g.hs] * r[0];
+                for (int t = 1; t <= g.hs; ++t) dx += sfs[g.hs + t] * (r[t * PW] + r[-t * PW]);
+                float dy = 0.f;
+                for (int t = 1; t <= g.hd; ++t) dy += sfd[g.hd + t] * (q[t * PW] - q[-t * PW]);
+                pc0 = dx * dx; pc1 = dx * dy; pc2 = dy * dy;
+                have = true;
+            }
+        }
+        if (have) { sC[e] = pc0; sC[PH * PW + e] = pc1; sC[2 * PH * PW + e] = pc2; }
+    }
+    __syncthreads();                     // R / Q are dead from here: the row sums take their place
+    for (int e = tid; e < PH * g.tx; e += 256) {
+        const int j = e / g.tx, i = e - j * g.tx;
+        const int x = x0 + i, cy = py0 + j;
+        if (x >= w || cy < 0 || cy >= h) continue;
+        const float* c = sC + j * PW;
+        const int i0 = vofe_reflect101(x - g.an, w) - px0;
+        double a0 = c[i0], a1 = c[PH * PW + i0], a2 = c[2 * PH * PW + i0];
+        for (int t = 1; t < g.bs; ++t) {
+            const int it = vofe_reflect101(x - g.an + t, w) - px0;
+            a0 += (double)c[it]; a1 += (double)c[PH * PW + it]; a2 += (double)c[2 * PH * PW + it];
+        }
+        sH[e] = a0; sH[PH * g.tx + e] = a1; sH[2 * PH * g.tx + e] = a2;
+    }
+    __syncthreads();
+    unsigned best = 0;
+    for (int e = tid; e < g.ty * g.tx; e += 256) {
+        const int j = e / g.tx, i = e - j * g.tx;
+        const int x = x0 + i, y = y0 + j;
+        if (x >= w || y >= h) continue;
+        const int j0 = (vofe_reflect101(y - g.an, h) - py0) * g.tx + i;
+        double t0 = sH[j0], t1 = sH[PH * g.tx + j0], t2 = sH[2 * PH * g.tx + j0];
+        for (int t = 1; t < g.bs; ++t) {
+            const int jt = (vofe_reflect101(y - g.an + t, h) - py0) * g.tx + i;
+            t0 += sH[jt]; t1 += sH[PH * g.tx + jt]; t2 += sH[2 * PH * g.tx + jt];
+        }
+        const float c0 = (float)t0, c1 = (float)t1, c2 = (float)t2;
+        float out;
+        if (!harris) {
+            const float a = c0 * 0.5f, b = c1, cc = c2 * 0.5f;
+            out = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+        } else {
+            out = (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2));
+        }
+        score[((size_t)blockIdx.z * h + y) * w + x] = out;
+        if (hdr && (!mask || mask[(size_t)y * w + x])) best = max(best, float_key(out));
+    }
+    if (hdr) {
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+        if ((tid & 63) == 0 && best) atomicMax(&sMax, best);
+        __syncthreads();
+        unsigned* slot = &hdr[blockIdx.z].max_key[(blockIdx.x + 5 * blockIdx.y) & (MAX_SLOTS - 1)];
+        if (tid == 0 && sMax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, sMax);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // score map, register-strip version (frames with w >= 8, h >= 4): one thread owns 4 adjacent columns
 // and walks RS output rows; no LDS.  Per image row it loads the 8 bytes covering columns x-2..x+5 with
 // one unaligned load, keeps a 3-row ring of the horizontal Sobel terms, a 3-row ring of the f64
@@ -1117,10 +1248,72 @@ int vofe_gftt_setup(vofe_ctx* ctx) {
     return ensure_pinned(ctx, sizeof(GfttHdr) / 4);
 }
 
+namespace {
+// cv::getSobelKernels for one axis (integer taps): binomial smoothing (order 0) or first derivative (order 1); a 1-tap
+// derivative request becomes the 3-tap [-1 0 1] as in OpenCV
+int sobel_taps(int ksize, int order, int* k) {
+    if (ksize == 1 && order > 0) ksize = 3;
+    int buf[9] = {0};
+    if (ksize == 1) buf[0] = 1;
+    else if (ksize == 3) {
+        if (order == 0) { buf[0] = 1; buf[1] = 2; buf[2] = 1; }
+        else { buf[0] = -1; buf[1] = 0; buf[2] = 1; }
+    } else {
+        buf[0] = 1;
+        for (int i = 0; i < ksize - order - 1; ++i) {
+            int oldval = buf[0];
+            for (int j = 1; j <= ksize; ++j) { const int nv = buf[j] + buf[j - 1]; buf[j - 1] = oldval; oldval = nv; }
+        }
+        for (int i = 0; i < order; ++i) {
+            int oldval = -buf[0];
+            for (int j = 1; j <= ksize; ++j) { const int nv = buf[j - 1] - buf[j]; buf[j - 1] = oldval; oldval = nv; }
+        }
+    }
+    for (int j = 0; j < ksize; ++j) k[j] = buf[j];
+    return ksize;
+}
+
+int launch_corner_score_generic(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch, size_t img_stride,
+                                int block, int aperture, int harris, float k, float* d_score, unsigned* d_hdr,
+                                const uint8_t* d_mask) {
+    ScoreGeom g = {};
+    g.bs = block; g.an = block / 2;
+    int dt[8], st[8];
+    g.ld = sobel_taps(aperture, 1, dt); g.ls = sobel_taps(aperture, 0, st);
+    g.hd = g.ld / 2; g.hs = g.ls / 2; g.hm = g.hd > g.hs ? g.hd : g.hs;
+    const double scale = 1.0 / ((double)(1 << (aperture - 1)) * block * 255.0);        // cornerEigenValsVecs, 8-bit input
+    for (int j = 0; j < g.ld; ++j) g.fd[j] = (float)dt[j];
+    for (int j = 0; j < g.ls; ++j) g.fs[j] = (float)((double)st[j] * scale);            // Mat * double, stored as f32
+    // the largest tile whose LDS plan fits 64 KiB (less the kernel's few static words); a tile side stays above
+    // blockSize / 2, so that an image longer than a tile is also longer than the box's overhang and reflected indices stay
+    // inside the tile's own region
+    static const int tiles[3][2] = {{64, 16}, {32, 16}, {16, 16}};
+    const size_t lds_max = 64 * 1024 - 256;
+    size_t lds = 0;
+    for (int t = 0; t < 3; ++t) {
+        g.tx = tiles[t][0]; g.ty = tiles[t][1];
+        lds = score_generic_lds(g);
+        if (lds <= lds_max) break;
+    }
+    if (lds > lds_max) { vofe_set_error("corner_score: blockSize %d / gradientSize %d needs %zu bytes of LDS", block, aperture, lds); return VOFE_E_UNSUPPORTED; }
+    dim3 grid((w + g.tx - 1) / g.tx, (h + g.ty - 1) / g.ty, batch);
+    if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
+    VOFE_TIMED(ctx, "corner_score_generic");
+    hipLaunchKernelGGL(corner_score_generic, grid, dim3(256), lds, ctx->stream, d_img, h, w, pitch, img_stride, g, harris, k,
+                       d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vofe_hip_fail(e, "corner_score_generic launch");
+    return VOFE_OK;
+}
+}  // namespace
+
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
-                             unsigned* d_hdr, const uint8_t* d_mask) {
+                             unsigned* d_hdr, const uint8_t* d_mask, int block_size, int aperture) {
     if (batch > 65535) { vofe_set_error("corner_score: batch too large"); return VOFE_E_UNSUPPORTED; }
+    if (block_size != 3 || aperture != 3 || ctx->knobs.score_generic)       // VOFE_CORNER_SCORE=generic: also block 3 / aperture 3 (tests)
+        return launch_corner_score_generic(ctx, d_img, batch, h, w, pitch, img_stride, block_size, aperture, harris, k, d_score,
+                                           d_hdr, d_mask);
     if (w >= 8 && h >= 4 && !ctx->knobs.score_tile) {            // VOFE_CORNER_SCORE=tile forces the LDS-tile kernel (tests)
         // strips of 8 rows; 4 rows while that leaves SIMDs without a wave (small frames are latency bound)
         long long waves8 = (long long)((w + 255) / 256) * ((h + 7) / 8) * batch;
@@ -1167,7 +1360,7 @@ int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out, float* h_corners_xy, bool noalloc) {
+                   int* h_n_out, float* h_corners_xy, bool noalloc, int block_size, int aperture) {
     hipStream_t st = ctx->stream;
     const size_t px = (size_t)h * w;
     if (px >= (1ull << 31)) { vofe_set_error("vofe_gftt: image too large"); return VOFE_E_UNSUPPORTED; }
@@ -1261,7 +1454,7 @@ int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w,
         VOFE_HIP(hipMemsetAsync(base, 0, hdr_bytes + hist_bytes, st));
     if (!noalloc) ctx->gftt_clean_batch = 0;
     rc = vofe_launch_corner_score(ctx, d_img, batch, h, w, pitch, img_stride, harris, (float)k, score,
-                                  reinterpret_cast<unsigned*>(hdr), d_mask);
+                                  reinterpret_cast<unsigned*>(hdr), d_mask, block_size, aperture);
     if (rc) return rc;
     // VOFE_GFTT_CHAIN=split keeps the longer chain of round 1 (tests: both chains must give the same corners)
     const bool merged = kn.gftt_chain != 's';     // VOFE_GFTT_CHAIN=split: the last stage as three launches (tests: same corners)

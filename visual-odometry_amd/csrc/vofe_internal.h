@@ -29,6 +29,7 @@ struct VofeKnobs {
     char pyramid;             // VOFE_PYRAMID: 'f'used | 'l'evels | 0 (size rule)
     bool pad_copy_generic;    // VOFE_PAD_COPY=generic: the any-width copy / border kernels
     bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
+    bool score_generic;       // VOFE_CORNER_SCORE=generic: the any-blockSize / any-aperture kernel for block 3 / aperture 3 too
     int score_rs;             // VOFE_SCORE_RS: rows per strip (0 = by launch size)
     bool pyr_step_off;        // VOFE_PYR_STEP=0: per-level path without the level pipeline (pyrDown + Scharr sharing launches)
     bool pyr_tail_off;        // VOFE_PYR_TAIL=0: level pipeline without its tail kernel (every level a pyrDown launch, the top level's Scharr pass alone)
@@ -117,7 +118,7 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
                    float min_eig_thr, int fb, float fb_thresh);
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
-                             unsigned* d_max_keys, const uint8_t* d_mask);
+                             unsigned* d_max_keys, const uint8_t* d_mask, int block_size = 3, int aperture = 3);
 int vofe_launch_new_feature_mask(vofe_ctx* ctx, const float* d_features_xy, int n_features,
                                  const float* d_existing_xy, int n_existing, const float* d_existing2_xy, int n_existing2,
                                  double threshold, uint8_t* d_mask);
@@ -141,7 +142,7 @@ int vofe_launch_candidate_commit(vofe_ctx* ctx, float* d_C, void* d_F, int first
 int vofe_gftt_impl(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                    size_t img_stride, int max_corners, double quality, double min_distance,
                    const uint8_t* d_mask, int harris, double k, float* d_corners_xy, int capacity,
-                   int* h_n_out, float* h_corners_xy = nullptr, bool noalloc = false);
+                   int* h_n_out, float* h_corners_xy = nullptr, bool noalloc = false, int block_size = 3, int aperture = 3);
 
 // ---- device helpers shared by kernels ------------------------------------------------------
 __device__ __forceinline__ int vofe_reflect101(int p, int n) {
