@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void corner_score_f32(const uint8_t* __restric
 // symmetric / antisymmetric column pass), products, f64 row sums of blockSize products, f64 column sums of blockSize row sums
 // (anchor blockSize / 2, REFLECT_101 on the product maps: indices are reflected when the sums read, products exist only at
 // image positions).  Operation order = oracle/vofe_oracle.cpp corner_score_generic, bit for bit.
+// REFLECT_101 with the in-range case first (all but a frame's outermost pixels): one unsigned compare instead of the loop
+__device__ __forceinline__ int refl101(int p, int n) { return (unsigned)p < (unsigned)n ? p : vofe_reflect101(p, n); }
 struct ScoreGeom {
     int bs, an;                  // box size and anchor
     int ld, hd, ls, hs, hm;      // derivative / smoothing tap counts, their half widths, image halo = max(hd, hs)
@@ -194,19 +196,24 @@ __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __res
     const int tid = threadIdx.x;
     if (tid == 0) sMax = 0;
     if (tid < 8) { sfd[tid] = g.fd[tid]; sfs[tid] = g.fs[tid]; }
+    // (row, column) of an element index advance with it: one division per loop instead of one per element
+#define SCORE_WALK(W) int j = tid / (W), i = tid - j * (W); const int dj_ = 256 / (W), di_ = 256 - dj_ * (W)
+#define SCORE_STEP(W) do { i += di_; j += dj_; if (i >= (W)) { i -= (W); ++j; } } while (0)
+    { SCORE_WALK(IW);
     for (int e = tid; e < IH * IW; e += 256) {
-        const int j = e / IW, i = e - j * IW;
-        const int sx = vofe_reflect101(px0 - g.hm + i, w), sy = vofe_reflect101(py0 - g.hm + j, h);
+        const int sx = refl101(px0 - g.hm + i, w), sy = refl101(py0 - g.hm + j, h);
         sI[e] = im[(size_t)sy * pitch + sx];
-    }
+        SCORE_STEP(IW);
+    } }
     __syncthreads();
     // row pass at every tile row (rows beyond the image are reflected copies, so their row-pass values are the reflected
     // rows' values), at image columns only
+    { SCORE_WALK(PW);
     for (int e = tid; e < IH * PW; e += 256) {
-        const int j = e / PW, i = e - j * PW;
         const int cx = px0 + i;
-        if (cx < 0 || cx >= w) continue;
         const uint8_t* p = sI + j * IW + i + g.hm;
+        SCORE_STEP(PW);
+        if (cx < 0 || cx >= w) continue;
         float r = sfd[0] * (float)p[-g.hd];
         for (int t = 1; t < g.ld; ++t) r += sfd[t] * (float)p[t - g.hd];
         float q;
@@ -216,15 +223,15 @@ __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __res
             for (int t = 1; t < g.ls; ++t) q += sfs[t] * (float)p[t - g.hs];
         }
         sR[e] = r; sQ[e] = q;
-    }
+    } }
     __syncthreads();
     // column pass and products at image positions of the product region
     float pc0 = 0.f, pc1 = 0.f, pc2 = 0.f;
+    { SCORE_WALK(PW);
     for (int e0 = 0; e0 < PH * PW; e0 += 256) {
         const int e = e0 + tid;
         bool have = false;
         if (e < PH * PW) {
-            const int j = e / PW, i = e - j * PW;
             const int cx = px0 + i, cy = py0 + j;
             if (cx >= 0 && cx < w && cy >= 0 && cy < h) {
                 const float* r = sR + (j + g.hm) * PW + i;
@@ -238,31 +245,35 @@ __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __res
             }
         }
         if (have) { sC[e] = pc0; sC[PH * PW + e] = pc1; sC[2 * PH * PW + e] = pc2; }
-    }
+        SCORE_STEP(PW);
+    } }
     __syncthreads();                     // R / Q are dead from here: the row sums take their place
+    { SCORE_WALK(g.tx);
     for (int e = tid; e < PH * g.tx; e += 256) {
-        const int j = e / g.tx, i = e - j * g.tx;
         const int x = x0 + i, cy = py0 + j;
-        if (x >= w || cy < 0 || cy >= h) continue;
         const float* c = sC + j * PW;
-        const int i0 = vofe_reflect101(x - g.an, w) - px0;
+        SCORE_STEP(g.tx);
+        if (x >= w || cy < 0 || cy >= h) continue;
+        const int i0 = refl101(x - g.an, w) - px0;
         double a0 = c[i0], a1 = c[PH * PW + i0], a2 = c[2 * PH * PW + i0];
         for (int t = 1; t < g.bs; ++t) {
-            const int it = vofe_reflect101(x - g.an + t, w) - px0;
+            const int it = refl101(x - g.an + t, w) - px0;
             a0 += (double)c[it]; a1 += (double)c[PH * PW + it]; a2 += (double)c[2 * PH * PW + it];
         }
         sH[e] = a0; sH[PH * g.tx + e] = a1; sH[2 * PH * g.tx + e] = a2;
-    }
+    } }
     __syncthreads();
     unsigned best = 0;
+    { SCORE_WALK(g.tx);
     for (int e = tid; e < g.ty * g.tx; e += 256) {
-        const int j = e / g.tx, i = e - j * g.tx;
         const int x = x0 + i, y = y0 + j;
+        const int ii = i;
+        SCORE_STEP(g.tx);
         if (x >= w || y >= h) continue;
-        const int j0 = (vofe_reflect101(y - g.an, h) - py0) * g.tx + i;
+        const int j0 = (refl101(y - g.an, h) - py0) * g.tx + ii;
         double t0 = sH[j0], t1 = sH[PH * g.tx + j0], t2 = sH[2 * PH * g.tx + j0];
         for (int t = 1; t < g.bs; ++t) {
-            const int jt = (vofe_reflect101(y - g.an + t, h) - py0) * g.tx + i;
+            const int jt = (refl101(y - g.an + t, h) - py0) * g.tx + ii;
             t0 += sH[jt]; t1 += sH[PH * g.tx + jt]; t2 += sH[2 * PH * g.tx + jt];
         }
         const float c0 = (float)t0, c1 = (float)t1, c2 = (float)t2;
@@ -275,7 +286,9 @@ __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __res
         }
         score[((size_t)blockIdx.z * h + y) * w + x] = out;
         if (hdr && (!mask || mask[(size_t)y * w + x])) best = max(best, float_key(out));
-    }
+    } }
+#undef SCORE_WALK
+#undef SCORE_STEP
     if (hdr) {
         for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
         if ((tid & 63) == 0 && best) atomicMax(&sMax, best);
