@@ -68,8 +68,8 @@ LK_PMC = {
 # corner_score_strip<16> on 128 KITTI frames per launch: instructions and cycles of the counter pass, and the issue bound its
 # instruction mix allows (profiles/r03_score_kernel_experiments.txt has the derivation and what was tried against it)
 SCORE_PMC = {
-    128: {"valu_instr": 72438656.0, "cycles": 2824546.7 / 8, "mix_bound_cycles_per_instr": 3.6,
-          "kernel_source": ("corners.hip", "92edc39f19a036d3"),
+    128: {"valu_instr": 72438656.0, "cycles": 2805773.0 / 8, "mix_bound_cycles_per_instr": 3.6,
+          "kernel_source": ("corners.hip", "01ecd1694d805a95"),
           "source": "profiles/r03_pmc_inst_v5.txt (SQ_INSTS_VALU, GRBM_GUI_ACTIVE / 8 XCDs; same counts as r03_pmc_inst_v1.txt: the strip "
                     "kernel is unchanged, corners.hip gained the any-geometry kernel); "
                     "mix: profiles/r03_score_kernel_experiments.txt"},

@@ -451,7 +451,7 @@ def test_corner_score_kernel_paths_and_edges(fe, knob, path):
                               oracle.goodFeaturesToTrack(a, 100, 0.01, 5, mask=mask))
 
 
-SCORE_GEOM = [(1, 3), (2, 3), (3, 1), (3, 5), (5, 3), (5, 5), (7, 7), (4, 7), (15, 5), (31, 1), (31, 7), (16, 3)]
+SCORE_GEOM = [(1, 3), (2, 3), (3, 1), (3, 5), (5, 3), (7, 3), (5, 5), (7, 7), (4, 7), (15, 5), (31, 1), (31, 7), (16, 3)]
 
 
 @pytest.mark.parametrize("block,ksize", SCORE_GEOM)
@@ -482,6 +482,11 @@ def test_generic_score_kernel_forced_for_the_default_geometry(fe, knob):
             assert np.array_equal(fe.corner_score(a, harris, 0.04), oracle.corner_score(a, harris, 0.04, nthreads=8)), (h, w, harris)
     a = _seq(376, 1241, 0, 1)[0]
     assert np.array_equal(fe.goodFeaturesToTrack(a, 1000, 0.01, 10), oracle.goodFeaturesToTrack(a, 1000, 0.01, 10, nthreads=8))
+    # the geometries with unrolled instances (5/3, 7/3, 3/5, 5/5) take the run-time instance under the switch: same maps
+    b = _seq(97, 131, 3, 1)[0]
+    for bs, ks in ((5, 3), (7, 3), (3, 5), (5, 5)):
+        for harris in (False, True):
+            assert np.array_equal(fe.corner_score(b, harris, 0.04, bs, ks), oracle.corner_score(b, harris, 0.04, blockSize=bs, ksize=ks)), (bs, ks)
 
 
 @pytest.mark.parametrize("block,ksize", [(5, 3), (7, 3), (3, 5), (7, 7), (2, 1), (11, 5)])

@@ -175,10 +175,23 @@ __host__ __device__ inline size_t score_generic_lds(const ScoreGeom& g) {
     const size_t rq = 8 * IH * PW, hsum = 24 * PH * (size_t)g.tx;
     return (rq > hsum ? rq : hsum) + 12 * PH * PW + ((IH * IW + 15) & ~(size_t)15);
 }
+// BS / KS > 0: that blockSize / aperture at compile time (the loops over taps and box entries unroll; same operations in the
+// same order), 0: run-time geometry.
+template <int BS, int KS>
 __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __restrict__ img, int h, int w, int pitch,
-                                                            size_t img_stride, ScoreGeom g, int harris, float kf,
+                                                            size_t img_stride, ScoreGeom gg, int harris, float kf,
                                                             float* __restrict__ score, GfttHdr* __restrict__ hdr,
                                                             const uint8_t* __restrict__ mask) {
+    struct G {
+        int tx, ty;
+        int bs, an, ld, hd, ls, hs, hm;
+    } g;
+    g.tx = gg.tx; g.ty = gg.ty;
+    if (BS) { g.bs = BS; g.an = BS / 2; } else { g.bs = gg.bs; g.an = gg.an; }
+    if (KS) {
+        g.ld = KS <= 3 ? 3 : KS; g.ls = KS == 1 ? 1 : KS;
+        g.hd = g.ld / 2; g.hs = g.ls / 2; g.hm = g.hd > g.hs ? g.hd : g.hs;
+    } else { g.ld = gg.ld; g.hd = gg.hd; g.ls = gg.ls; g.hs = gg.hs; g.hm = gg.hm; }
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float sfd[8], sfs[8];
     __shared__ unsigned sMax;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256) void corner_score_generic(const uint8_t* __res
     const uint8_t* im = img + (size_t)blockIdx.z * img_stride;
     const int tid = threadIdx.x;
     if (tid == 0) sMax = 0;
-    if (tid < 8) { sfd[tid] = g.fd[tid]; sfs[tid] = g.fs[tid]; }
+    if (tid < 8) { sfd[tid] = gg.fd[tid]; sfs[tid] = gg.fs[tid]; }
     // (row, column) of an element index advance with it: one division per loop instead of one per element
 #define SCORE_WALK(W) int j = tid / (W), i = tid - j * (W); const int dj_ = 256 / (W), di_ = 256 - dj_ * (W)
 #define SCORE_STEP(W) do { i += di_; j += dj_; if (i >= (W)) { i -= (W); ++j; } } while (0)
@@ -1312,8 +1325,17 @@ int launch_corner_score_generic(vofe_ctx* ctx, const uint8_t* d_img, int batch, 
     dim3 grid((w + g.tx - 1) / g.tx, (h + g.ty - 1) / g.ty, batch);
     if (grid.y > 65535) { vofe_set_error("corner_score: image too large"); return VOFE_E_UNSUPPORTED; }
     VOFE_TIMED(ctx, "corner_score_generic");
-    hipLaunchKernelGGL(corner_score_generic, grid, dim3(256), lds, ctx->stream, d_img, h, w, pitch, img_stride, g, harris, k,
-                       d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask);
+#define SCORE_GEOM_LAUNCH(B, K) hipLaunchKernelGGL((corner_score_generic<B, K>), grid, dim3(256), lds, ctx->stream, d_img, h, w, pitch, \
+                                                   img_stride, g, harris, k, d_score, reinterpret_cast<GfttHdr*>(d_hdr), d_mask)
+    // the geometries a cv2 user is most likely to pass get unrolled instances (OpenCV's own optical-flow example uses
+    // blockSize 7); VOFE_CORNER_SCORE=generic keeps the run-time instance for all of them (tests compare the two)
+    const bool rt = ctx->knobs.score_generic;
+    if (!rt && block == 5 && aperture == 3) SCORE_GEOM_LAUNCH(5, 3);
+    else if (!rt && block == 7 && aperture == 3) SCORE_GEOM_LAUNCH(7, 3);
+    else if (!rt && block == 3 && aperture == 5) SCORE_GEOM_LAUNCH(3, 5);
+    else if (!rt && block == 5 && aperture == 5) SCORE_GEOM_LAUNCH(5, 5);
+    else SCORE_GEOM_LAUNCH(0, 0);
+#undef SCORE_GEOM_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vofe_hip_fail(e, "corner_score_generic launch");
     return VOFE_OK;
