@@ -527,6 +527,16 @@ def test_gftt_with_block_size_and_gradient_size(fe, block, ksize):
     assert one.value == ref.shape[0] and np.array_equal(o1[:one.value].cpu().numpy(), ref.reshape(-1, 2))
 
 
+def test_cv2_output_placeholder_keywords_are_accepted(fe):
+    """cv2's bindings take optional output placeholders (corners=, status=, err=); callers that name them keep working."""
+    a, b = _seq(64, 80, 2)
+    c = fe.goodFeaturesToTrack(a, maxCorners=20, qualityLevel=0.01, minDistance=5, corners=None, mask=None, blockSize=3)
+    assert np.array_equal(c, oracle.goodFeaturesToTrack(a, 20, 0.01, 5))
+    n, s, e = fe.calcOpticalFlowPyrLK(a, b, c, None, status=None, err=None, winSize=(11, 11), maxLevel=1)
+    n2, s2, e2 = oracle.calcOpticalFlowPyrLK(a, b, c, None, (11, 11), 1)
+    assert np.array_equal(n, n2) and np.array_equal(s, s2)
+
+
 def test_block_size_and_gradient_size_argument_errors(fe):
     """cv2 raises for blockSize < 1 and for an even aperture; apertures above 7 and blocks above 31 are refused here with a
     message that says so (cv2 would run them)."""

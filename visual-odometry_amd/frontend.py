@@ -260,7 +260,10 @@ class FrontEnd:
 
     # -------------------------------------------------------------------------------- cv2 twins
     def calcOpticalFlowPyrLK(self, prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
-                             criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
+                             criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4, status=None, err=None):
+        """cv2.calcOpticalFlowPyrLK.  `status` / `err` are cv2's optional output placeholders: accepted by keyword and
+        ignored (cv2's binding returns fresh arrays as well); the reference passes everything behind nextPts by keyword
+        (continuous.py:145-151)."""
         p = self._points(prevPts)
         n = p.shape[0]
         pair = self._frame_pair(prevImg, nextImg, "prevImg and nextImg must have the same size")
@@ -324,7 +327,8 @@ class FrontEnd:
         return out.cpu().numpy()
 
     def goodFeaturesToTrack(self, image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
-                            useHarrisDetector=False, k=0.04, gradientSize=3):
+                            useHarrisDetector=False, k=0.04, gradientSize=3, corners=None):
+        """cv2.goodFeaturesToTrack.  `corners` is cv2's optional output placeholder: accepted by keyword and ignored."""
         a = self.to_device(image)
         h, w = a.shape
         cap = int(maxCorners) if maxCorners > 0 else h * w
@@ -596,13 +600,13 @@ def default_frontend():
 
 
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None, blockSize=3,
-                        useHarrisDetector=False, k=0.04, gradientSize=3):
+                        useHarrisDetector=False, k=0.04, gradientSize=3, corners=None):
     return default_frontend().goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask, blockSize,
                                                   useHarrisDetector, k, gradientSize)
 
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
-                         criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4):
+                         criteria=_DEFAULT_CRITERIA, flags=0, minEigThreshold=1e-4, status=None, err=None):
     return default_frontend().calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria,
                                                    flags, minEigThreshold)
 
