@@ -89,7 +89,10 @@ int vofe_pyramid_download_padded(vofe_ctx* ctx, const vofe_pyr* pyr, int slot, i
  * lost (status 0, err 0) and never addresses memory outside the batch.  n_images is ignored (1) when
  * d_img_idx is NULL.  d_prev_pts / d_next_pts are (n,2) f32 xy; d_next_pts is read only with
  * VOFE_OPTFLOW_USE_INITIAL_FLOW.  d_status (n) u8, d_err (n) f32 (entries cv2 leaves
- * uninitialised are written as 0). */
+ * uninitialised are written as 0).  Any window the pyramids were created for is tracked: up to 64
+ * columns (and 64 rows per lane group) by the wavefront-per-keypoint kernels, larger ones by a
+ * workgroup-per-keypoint kernel whose template window must fit 64 KiB of LDS (win_w * win_h <=
+ * 10 880, about 104x104; VOFE_E_UNSUPPORTED beyond). */
 int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next,
                   int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                   uint8_t* d_status, float* d_err, int n, int crit_type, int max_count, double eps,

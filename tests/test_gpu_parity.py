@@ -270,6 +270,98 @@ def test_lk_ragged_compile_time_windows(fe, knob, win, kernel):
     assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
 
 
+@pytest.mark.parametrize("win", [(21, 21), (11, 11), (9, 15), (31, 17), (5, 5)])
+def test_lk_wide_window_fallback_forced_on_small_windows(fe, knob, win):
+    """VOFE_LK=wide sends every launch through the workgroup-per-keypoint fallback (lk_wide.hip): on windows the
+    wavefront kernels also handle it must return the oracle's results bit for bit -- tracking, flags, the FB twin, a ragged
+    batch of sequences, wild points, flat frames, extreme contrast."""
+    import torch
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import Pyramid
+    knob("VOFE_LK", "wide")
+    a, b = _seq(240, 320, 21)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 301, 0.01, 7), 301, 240, 320, 21)
+    for lvl in (3, 0):
+        exact, _, st = _lk_compare(fe, a, b, pts, win, lvl)
+        assert exact and st.sum() > 150
+    init = (pts + np.float32([1.0, 0.5])).astype(np.float32)
+    assert _lk_compare(fe, a, b, pts, win, 2, flags=4, init=init)[0]
+    assert _lk_compare(fe, a, b, pts, win, 2, flags=8, min_eig=1e-3)[0]
+    assert _lk_compare(fe, a, b, pts, win, 2, criteria=(1, 5, 0.01))[0]
+    assert _lk_compare(fe, a, b, pts, win, 2, criteria=(2, 30, 0.5))[0]
+    t1 = fe.track_keypoints(pts.T, a, b, winSize=win)
+    t0 = oracle.track_keypoints(pts.T, a, b, winSize=win, nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
+    wild = np.float32([[-30, 5], [5, -30], [400, 50], [50, 400], [-5.5, -5.5], [319.9, 239.9], [0, 0],
+                       [80, 60], [np.nan, 3], [1e12, 1e12], [-1e20, 4], [np.inf, 0], [100, 100]])
+    flat = np.full_like(a, 77)
+    for (x, y) in ((a, b), (flat, flat), (a, flat)):
+        n1, s1, e1 = fe.calcOpticalFlowPyrLK(x, y, wild, None, win, 2)
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(x, y, wild, None, win, 2)
+        assert np.array_equal(s0, s1) and np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True)
+    rng = np.random.default_rng(18)
+    hc = np.kron((rng.random((60, 80)) > 0.5).astype(np.uint8) * 255, np.ones((4, 4), np.uint8))
+    hd = np.roll(hc, (1, 2), axis=(0, 1))
+    p2 = (rng.random((101, 2)) * [319, 239]).astype(np.float32)
+    n0, s0, e0 = oracle.calcOpticalFlowPyrLK(hc, hd, p2, None, win, 2, (3, 30, 0.01), 0, 1e-4, nthreads=8)
+    n1, s1, e1 = fe.calcOpticalFlowPyrLK(hc, hd, p2, None, win, 2, (3, 30, 0.01), 0, 1e-4)
+    assert np.array_equal(s0, s1) and np.array_equal(n0, n1) and np.array_equal(e0, e1)
+    # a ragged batch: three sequences in one launch through the image index, one index out of range
+    seqs = [_seq(120, 160, 40 + k) for k in range(3)]
+    imgs = torch.from_numpy(np.stack([q[0] for q in seqs] + [q[1] for q in seqs])).cuda()
+    pyr = Pyramid(fe, 6, 120, 160, win, 2, True)
+    pyr.build(imgs, 0)
+    ps = [synthetic.pad_points(oracle.goodFeaturesToTrack(q[0], 40 + 7 * k, 0.01, 5), 40 + 7 * k, 120, 160, k) for k, q in enumerate(seqs)]
+    allp = np.concatenate(ps)
+    idx = np.concatenate([np.full(len(q), k, np.int32) for k, q in enumerate(ps)])
+    idx[5] = 7                                                   # outside the batch: the point is reported lost
+    d_p, d_i = torch.from_numpy(allp).cuda(), torch.from_numpy(idx).cuda()
+    n = len(allp)
+    nxt = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    st = torch.empty(n, dtype=torch.uint8, device="cuda")
+    er = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(fe.L.vofe_track_fb(fe.ctx, pyr._h, 0, pyr._h, 3, d_p.data_ptr(), d_i.data_ptr(), 3, nxt.data_ptr(), st.data_ptr(),
+                                  er.data_ptr(), n, 3, 30, 0.01, 1e-3, 1.0))
+    fe.synchronize()
+    nxt, st, er = nxt.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+    o = 0
+    for k, q in enumerate(seqs):
+        t0, s0, e0 = oracle.track_keypoints(ps[k].T, q[0], q[1], win, 2)
+        sl = slice(o, o + len(ps[k]))
+        keep = idx[sl] == k
+        assert np.array_equal(nxt[sl][keep], t0.T[keep]) and np.array_equal(st[sl][keep], s0[keep])
+        assert np.array_equal(er[sl][keep & (s0 == 1)], e0[keep & (s0 == 1)])
+        o += len(ps[k])
+    assert st[5] == 0 and er[5] == 0
+    pyr.free()
+
+
+@pytest.mark.parametrize("win,lvl", [((65, 65), 2), ((101, 101), 1), ((71, 33), 2), ((33, 71), 1), ((3, 200), 0), ((104, 104), 0)])
+def test_lk_windows_beyond_the_wavefront_kernels(fe, win, lvl):
+    """cv2.calcOpticalFlowPyrLK takes any winSize; windows wider than 64 columns (or taller than 64 rows per lane group) run the
+    workgroup-per-keypoint fallback.  Against the oracle, bit for bit, incl. the FB twin and points whose window hangs over
+    the frame's edge."""
+    a, b = _seq(300, 400, 33)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 120, 0.01, 9), 128, 300, 400, 33)
+    exact, _, st = _lk_compare(fe, a, b, pts, win, lvl)
+    assert exact and st.sum() > 60
+    assert _lk_compare(fe, a, b, pts, win, lvl, flags=8, min_eig=1e-3)[0]
+    t1 = fe.track_keypoints(pts.T, a, b, winSize=win, maxLevel=lvl)
+    t0 = oracle.track_keypoints(pts.T, a, b, winSize=win, maxLevel=lvl, nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(t1, t0))
+    edge = np.float32([[0, 0], [399, 299], [-40, 20], [20, -40], [430, 150], [200, 340], [1.5, 298.5], [np.nan, 3], [1e12, 5]])
+    n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, edge, None, win, lvl)
+    n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, edge, None, win, lvl)
+    assert np.array_equal(s0, s1) and np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True)
+
+
+def test_lk_window_too_large_for_the_fallback_is_refused(fe):
+    from visual_odometry_amd import error
+    a, b = _seq(300, 400, 33)
+    with pytest.raises(error):
+        fe.calcOpticalFlowPyrLK(a, b, np.float32([[100, 100]]), None, (121, 121), 0)
+
+
 @pytest.mark.parametrize("ppw", ["x1", "lp", "x2", "x2p", "x4"])
 def test_lk_21x21_kernel_families(fe, knob, ppw):
     """The 21x21 kernel families, each forced on the same small inputs: one keypoint per wavefront (x1), one wavefront

@@ -185,6 +185,20 @@ def test_lk_matches_twin(win, lvl, flags):
     assert np.array_equal(e0.ravel(), e1)
 
 
+def test_lk_wide_windows_match_twin():
+    """Windows beyond 64 columns / rows (cv2 takes any winSize; the GPU runs them on its workgroup-per-keypoint fallback): the
+    C++ restatement against the numpy twin, and its AVX2 loops against its scalar loops."""
+    a, b = synthetic.sequence(150, 200, 8, 2)
+    pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 6, 0.01, 20), 8, 150, 200, 8)
+    for win, lvl in (((71, 71), 1), ((33, 67), 0)):
+        n0, s0, e0 = oracle.calcOpticalFlowPyrLK(a, b, pts, None, win, lvl, (3, 30, 0.01), 0, 1e-4)
+        n1, s1, e1 = T.lk(a, b, pts, win, lvl, 30, 0.01, 0, 1e-4, None)
+        assert np.array_equal(n0.reshape(-1, 2), n1) and np.array_equal(s0.ravel(), s1) and np.array_equal(e0.ravel(), e1)
+        with oracle.simd():
+            n2, s2, e2 = oracle.calcOpticalFlowPyrLK(a, b, pts, None, win, lvl, (3, 30, 0.01), 0, 1e-4)
+        assert np.array_equal(n0, n2) and np.array_equal(s0, s2) and np.array_equal(e0, e2)
+
+
 def test_oracle_thread_count_invariance():
     a, b = synthetic.sequence(120, 160, 6, 2)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 150, 0.01, 5), 200, 120, 160, 6)

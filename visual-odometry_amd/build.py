@@ -3,7 +3,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "pyramid.hip", "lk.hip", "corners.hip", "bookkeeping.hip", "framestate.hip"]
+SOURCES = ["api.hip", "pyramid.hip", "lk.hip", "lk_wide.hip", "corners.hip", "bookkeeping.hip", "framestate.hip"]
 # -ffp-contract=off: the float steps must round exactly like the CPU oracle (no fused multiply-add)
 # -dot4-insts: without v_dot2c_i32_i16 (accumulator tied to the destination) the compiler selects the three-source
 # v_dot2_i32_i16, which costs the same issue time and needs no v_mov to keep the seed of every bilinear sample alive

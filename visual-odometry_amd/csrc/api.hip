@@ -309,6 +309,9 @@ int vofe_lk_track(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
     if (rc || n == 0) return rc;
     VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
+    if (vofe_lk_needs_wide(prev->win_w, prev->win_h) || ctx->knobs.lk[0] == 'w')
+        return vofe_launch_lk_wide(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err,
+                                   n, max_count, eps, flags, (float)min_eig_thr, 0, 0.f);
     return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err, n,
                           max_count, eps, flags, (float)min_eig_thr, 0, 0.f);
 }
@@ -322,6 +325,9 @@ int vofe_track_fb(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe
     if (rc || n == 0) return rc;
     VOFE_BIND(ctx);
     lk_criteria(crit_type, max_count, eps);
+    if (vofe_lk_needs_wide(prev->win_w, prev->win_h) || ctx->knobs.lk[0] == 'w')
+        return vofe_launch_lk_wide(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err,
+                                   n, max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
     return vofe_launch_lk(ctx, prev, prev_slot, next, next_slot, d_prev_pts, d_img_idx, n_images, d_next_pts, d_status, d_err, n,
                           max_count, eps, 0, (float)min_eig_thr, 1, fb_thresh);
 }

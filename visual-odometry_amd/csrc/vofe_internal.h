@@ -25,7 +25,7 @@ struct VofeLevel {
 // VOFE_* environment switches (tests, tuning, measurements).  Read ONCE per context at vofe_create -- not on the
 // launch paths, whose latency is measured in tens of microseconds -- and again by vofe_reload_env (tests).
 struct VofeKnobs {
-    char lk[8];               // VOFE_LK: "generic" | "x1" | "x2" | "x4" | "" (size rule)
+    char lk[8];               // VOFE_LK: "generic" | "x1" | "x2" | "x4" | "lp" | "wide" | "" (size rule)
     char pyramid;             // VOFE_PYRAMID: 'f'used | 'l'evels | 0 (size rule)
     bool pad_copy_generic;    // VOFE_PAD_COPY=generic: the any-width copy / border kernels
     bool score_tile;          // VOFE_CORNER_SCORE=tile: the LDS-tile score kernel
@@ -116,6 +116,11 @@ int vofe_launch_lk(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vof
                    int next_slot, const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts,
                    uint8_t* d_status, float* d_err, int n, int max_count, double eps2, int flags,
                    float min_eig_thr, int fb, float fb_thresh);
+// wide-window fallback (lk_wide.hip): windows the wavefront-per-keypoint kernels cannot hold, or every launch under VOFE_LK=wide
+bool vofe_lk_needs_wide(int win_w, int win_h);
+int vofe_launch_lk_wide(vofe_ctx* ctx, const vofe_pyr* prev, int prev_slot, const vofe_pyr* next, int next_slot,
+                        const float* d_prev_pts, const int* d_img_idx, int n_images, float* d_next_pts, uint8_t* d_status,
+                        float* d_err, int n, int max_count, double eps2, int flags, float min_eig_thr, int fb, float fb_thresh);
 int vofe_launch_corner_score(vofe_ctx* ctx, const uint8_t* d_img, int batch, int h, int w, int pitch,
                              size_t img_stride, int harris, float k, float* d_score,
                              unsigned* d_max_keys, const uint8_t* d_mask, int block_size = 3, int aperture = 3);
