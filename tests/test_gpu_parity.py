@@ -1657,7 +1657,8 @@ def test_real_stereo_pair_tracking(fe):
 # ------------------------------------------------------------------ seeded randomised differential sweeps
 def test_randomised_lk_sweep_all_window_shapes(fe):
     """40 random (image size, window, levels, criteria, flags) combinations: every row-group template of the
-    run-time-geometry kernel (windows 3..64 wide, 3..64 tall) against the oracle, bit for bit."""
+    run-time-geometry kernel (windows 3..64 wide, 3..64 tall) and, on every eighth case, a window beyond them (the
+    workgroup-per-keypoint fallback) against the oracle, bit for bit."""
     import os
     rng = np.random.default_rng(int(os.environ.get("VOFE_SWEEP_SEED", 2024)))       # soak runs: other seeds, more cases
     seen_r = set()
@@ -1666,6 +1667,8 @@ def test_randomised_lk_sweep_all_window_shapes(fe):
         ww, wh = int(rng.integers(3, 65)), int(rng.integers(3, 65))
         if case < 10:                                   # make sure the extremes are in
             ww, wh = [(3, 3), (64, 64), (64, 3), (3, 64), (5, 41), (33, 7), (21, 22), (22, 21), (13, 13), (47, 31)][case]
+        elif case % 8 == 5:                             # beyond the wavefront kernels: the workgroup-per-keypoint fallback
+            ww, wh = [(int(rng.integers(65, 104)), int(rng.integers(3, 100))), (int(rng.integers(33, 64)), int(rng.integers(65, 120)))][case % 16 == 5]
         lvl = int(rng.integers(0, 4))
         a, b = _seq(h, w, 300 + case)
         pts = np.concatenate([(rng.random((40, 2)) * [w - 1, h - 1]), rng.normal(0, 30, (6, 2)) + [w, h]]).astype(np.float32)
@@ -1677,8 +1680,9 @@ def test_randomised_lk_sweep_all_window_shapes(fe):
         n1, s1, e1 = fe.calcOpticalFlowPyrLK(a, b, pts, init, (ww, wh), lvl, crit, flags, mineig)
         assert np.array_equal(s0, s1), (case, h, w, ww, wh, lvl)
         assert np.array_equal(n0, n1, equal_nan=True) and np.array_equal(e0, e1, equal_nan=True), (case, h, w, ww, wh, lvl)
-        groups = min(64 // ww, wh)
-        seen_r.add(-(-wh // groups))
+        if ww <= 64:
+            groups = min(64 // ww, wh)
+            seen_r.add(-(-wh // groups))
     assert len(seen_r) >= 12
 
 
