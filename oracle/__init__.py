@@ -182,7 +182,9 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
                                  int(nthreads))
     if rc:
         raise ValueError("vofe_cpu_lk_track: bad arguments (rc=%d)" % rc)
-    return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
+    shape = np.shape(prevPts)                      # cv2: nextPts takes prevPts' own layout, status / err are (N,1)
+    return (nxt.reshape(shape if len(shape) in (2, 3) and shape[-1] == 2 else (-1, 1, 2)), st.reshape(-1, 1),
+            err.reshape(-1, 1))
 
 
 def track_keypoints(prev_keypoints, img_prev, img_current, winSize=(21, 21), maxLevel=3,

@@ -619,6 +619,21 @@ def test_gftt_with_block_size_and_gradient_size(fe, block, ksize):
     assert one.value == ref.shape[0] and np.array_equal(o1[:one.value].cpu().numpy(), ref.reshape(-1, 2))
 
 
+def test_next_points_take_the_layout_of_prev_points_as_in_cv2(fe):
+    """cv2 creates nextPts with prevPts' own layout: (N,1,2) in -> (N,1,2) out (what the reference passes,
+    continuous.py:134-135), (N,2) in -> (N,2) out, (1,N,2) in -> (1,N,2) out; status and err are (N,1) always."""
+    a, b = _seq(64, 80, 2)
+    c = fe.goodFeaturesToTrack(a, 20, 0.01, 5)
+    n = c.shape[0]
+    ref = fe.calcOpticalFlowPyrLK(a, b, c, None, (11, 11), 1)
+    assert ref[0].shape == (n, 1, 2) and ref[1].shape == (n, 1) and ref[2].shape == (n, 1)
+    for shape in ((n, 2), (1, n, 2)):
+        got = fe.calcOpticalFlowPyrLK(a, b, c.reshape(shape), None, (11, 11), 1)
+        assert got[0].shape == shape and got[1].shape == (n, 1) and got[2].shape == (n, 1)
+        assert np.array_equal(got[0].reshape(-1, 2), ref[0].reshape(-1, 2)) and np.array_equal(got[1], ref[1])
+        assert oracle.calcOpticalFlowPyrLK(a, b, c.reshape(shape), None, (11, 11), 1)[0].shape == shape
+
+
 def test_cv2_output_placeholder_keywords_are_accepted(fe):
     """cv2's bindings take optional output placeholders (corners=, status=, err=); callers that name them keep working."""
     a, b = _seq(64, 80, 2)

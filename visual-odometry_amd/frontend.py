@@ -97,6 +97,12 @@ class Pyramid:
             pass
 
 
+def _points_shape(prevPts):
+    """The shape cv2.calcOpticalFlowPyrLK gives nextPts: that of prevPts when it is (N,2), (N,1,2) or (1,N,2)."""
+    shape = np.shape(prevPts)
+    return shape if len(shape) in (2, 3) and shape[-1] == 2 else (-1, 1, 2)
+
+
 class FrontEnd:
     """One context = one GPU + one stream (the current torch stream of `device` at construction)."""
 
@@ -286,7 +292,8 @@ class FrontEnd:
                                             float(criteria[2]), int(flags), float(minEigThreshold)))
             nxt, st, err = self._unpack_outputs(buf, n)
         self.synchronize()                        # the staging buffer is free again only once this stream has drained
-        return nxt.reshape(-1, 1, 2), st.reshape(-1, 1), err.reshape(-1, 1)
+        # cv2 creates nextPts with prevPts' own layout ((N,1,2) in -> (N,1,2) out, (N,2) in -> (N,2) out); status / err are (N,1)
+        return nxt.reshape(_points_shape(prevPts)), st.reshape(-1, 1), err.reshape(-1, 1)
 
     def _frame_pair(self, img_a, img_b, msg):
         """(2,H,W) device tensor of two frames: host arrays travel together through the staging buffer."""
