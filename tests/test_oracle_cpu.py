@@ -199,6 +199,87 @@ def test_lk_wide_windows_match_twin():
         assert np.array_equal(n0, n2) and np.array_equal(s0, s2) and np.array_equal(e0, e2)
 
 
+def _float_lk(prev_img, next_img, pts, win, max_level, max_count=30, eps=0.01, min_eig_thr=1e-4):
+    """Pyramidal Lucas-Kanade in plain float64 -- the algorithm of Bouguet's report that OpenCV implements, WITHOUT OpenCV's
+    fixed-point steps (14-bit integer bilinear weights, intensities kept with 5 fractional bits, derivatives rounded to
+    int16, float32 sums): exact bilinear samples of the same u8 pyramid and the same integer Scharr planes, float64 sums and
+    solve, the same level loop, window placement and stopping rules."""
+    w, h = win
+    Ps, Ns = T.pyramid(prev_img, win, max_level), T.pyramid(next_img, win, max_level)
+    I = [T._pad101(p.astype(np.float64), ((h, h), (w, w))) for p in Ps]
+    J = [T._pad101(p.astype(np.float64), ((h, h), (w, w))) for p in Ns]
+    D = [np.pad(T.scharr(p).astype(np.float64), ((h, h), (w, w), (0, 0))) for p in Ps]
+    hx, hy = (w - 1) * 0.5, (h - 1) * 0.5
+
+    def sample(P, fx, fy):
+        ix, iy = int(np.floor(fx)), int(np.floor(fy))
+        a, b = fx - ix, fy - iy
+        q = P[iy + h:iy + h + h + 1, ix + w:ix + w + w + 1]
+        return (1 - a) * (1 - b) * q[:-1, :-1] + a * (1 - b) * q[:-1, 1:] + (1 - a) * b * q[1:, :-1] + a * b * q[1:, 1:]
+
+    out, st = np.zeros((len(pts), 2)), np.ones(len(pts), np.uint8)
+    top = len(Ps) - 1
+    for i, (px, py) in enumerate(np.asarray(pts, np.float64)):
+        ox = oy = 0.0
+        for L in range(top, -1, -1):
+            sc = 1.0 / (1 << L)
+            ppx, ppy = px * sc - hx, py * sc - hy
+            npx, npy = (px * sc, py * sc) if L == top else (ox * 2, oy * 2)
+            ox, oy = npx, npy
+            rows, cols = Ps[L].shape
+            if not (-w <= np.floor(ppx) < cols and -h <= np.floor(ppy) < rows):
+                if L == 0:
+                    st[i] = 0
+                continue
+            Ip, Ix, Iy = sample(I[L], ppx, ppy), sample(D[L][..., 0], ppx, ppy), sample(D[L][..., 1], ppx, ppy)
+            # OpenCV's units (its thresholds are stated in them): derivatives in raw Scharr units, differences times 32, sums 2^-20
+            A11, A12, A22 = (Ix * Ix).sum() / (1 << 20), (Ix * Iy).sum() / (1 << 20), (Iy * Iy).sum() / (1 << 20)
+            det = A11 * A22 - A12 * A12
+            me = (A22 + A11 - np.sqrt((A11 - A22) ** 2 + 4 * A12 * A12)) / (2 * w * h)
+            if me < min_eig_thr or det < 1.1920928955078125e-07:
+                if L == 0:
+                    st[i] = 0
+                continue
+            npx, npy = npx - hx, npy - hy
+            pdx = pdy = 0.0
+            for j in range(max_count):
+                if not (-w <= np.floor(npx) < cols and -h <= np.floor(npy) < rows):
+                    if L == 0:
+                        st[i] = 0
+                    break
+                diff = (sample(J[L], npx, npy) - Ip) * 32.0
+                b1, b2 = (diff * Ix).sum() / (1 << 20), (diff * Iy).sum() / (1 << 20)
+                dx, dy = (A12 * b2 - A22 * b1) / det, (A12 * b1 - A11 * b2) / det
+                npx, npy = npx + dx, npy + dy
+                ox, oy = npx + hx, npy + hy
+                if dx * dx + dy * dy <= eps * eps:
+                    break
+                if j > 0 and abs(dx + pdx) < 0.01 and abs(dy + pdy) < 0.01:
+                    ox, oy = ox - dx * 0.5, oy - dy * 0.5
+                    break
+                pdx, pdy = dx, dy
+        out[i] = (ox, oy)
+    return out, st
+
+
+@pytest.mark.parametrize("h,w,seed,win,lvl", [(240, 320, 5, (21, 21), 3), (200, 260, 9, (11, 11), 2), (240, 320, 6, (31, 31), 2)])
+def test_lk_fixed_point_steps_stay_close_to_the_exact_float_algorithm(h, w, seed, win, lvl):
+    """What only cv2 could pin is the tracker's fixed-point detail.  What CAN be bounded without cv2 is how far those steps
+    (as restated) move a track away from the same algorithm in exact float arithmetic: they are roundings at the 2^-5
+    intensity / 2^-14 weight level, so the two must agree to a few thousandths of a pixel wherever the walk is not bistable."""
+    a, b = synthetic.sequence(h, w, seed, 2)
+    c = oracle.goodFeaturesToTrack(a, 150, 0.01, 7).reshape(-1, 2)
+    n0, s0, _ = oracle.calcOpticalFlowPyrLK(a, b, c, None, win, lvl, (3, 30, 0.01), 0, 1e-4)
+    n1, s1 = _float_lk(a, b, c, win, lvl)
+    s0 = s0.ravel()
+    assert np.mean(s0 == s1) >= 0.99
+    ok = (s0 == 1) & (s1 == 1)
+    assert ok.sum() > 100
+    d = np.abs(n0 - n1).max(1)[ok]
+    # measured: median 4e-5 px, maximum 1.5e-4 px, identical status flags (DESIGN.md section 3)
+    assert np.median(d) < 5e-4 and np.mean(d < 2e-3) >= 0.98 and d.max() < 0.05, (np.median(d), d.max())
+
+
 def test_oracle_thread_count_invariance():
     a, b = synthetic.sequence(120, 160, 6, 2)
     pts = synthetic.pad_points(oracle.goodFeaturesToTrack(a, 150, 0.01, 5), 200, 120, 160, 6)
