@@ -143,10 +143,12 @@ def corner_score_generic(img, block=3, ksize=3, harris=False, k=0.04):
     return (c0 * c2 - c1 * c1) - kf * ((c0 + c2) * (c0 + c2))
 
 
-def gftt(img, max_corners, quality, min_distance, mask=None, harris=False, k=0.04, block=3, ksize=3):
+def gftt(img, max_corners, quality, min_distance, mask=None, harris=False, k=0.04, block=3, ksize=3, eig=None):
     """A.2, sequential greedy with a brute-force distance test (no grid: A.2 step 6 shows the grid
-    never changes the outcome because cell >= minDistance - 0.5)."""
-    eig = corner_score(img, harris, k) if (block == 3 and ksize == 3) else corner_score_generic(img, block, ksize, harris, k)
+    never changes the outcome because cell >= minDistance - 0.5).  `eig`: a score map to select from instead of this
+    module's own (tests feed scipy's float64 evaluation of the definition)."""
+    if eig is None:
+        eig = corner_score(img, harris, k) if (block == 3 and ksize == 3) else corner_score_generic(img, block, ksize, harris, k)
     h, w = eig.shape
     sel = eig if mask is None else eig[mask != 0]
     if sel.size == 0:

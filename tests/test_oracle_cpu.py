@@ -548,6 +548,26 @@ def test_gftt_with_block_and_gradient_size_matches_twin(block, ksize):
         oracle.goodFeaturesToTrack(a, 10, 0.01, 5, gradientSize=4)
 
 
+@pytest.mark.parametrize("h,w,seed,maxc,md", [(376, 1241, 0, 2000, 7), (480, 640, 3, 1000, 10), (600, 800, 1, 1000, 10)])
+def test_corner_lists_from_scipys_float64_score_map_equal_the_oracles(h, w, seed, maxc, md):
+    """The whole detector on the reference's frame shapes with NOTHING of the float32 restatement in the score map: Sobel / box
+    sums / minimum eigenvalue evaluated by scipy.ndimage in float64 from the published definition, the selection rule (threshold,
+    3x3 maxima, order, greedy minDistance) by the numpy twin.  The corner LISTS -- sets and order -- must equal the oracle's:
+    the float32 operation order, which is what cannot be pinned without cv2, does not decide a single corner on these frames."""
+    from scipy import ndimage
+    img = _texture(h, w, seed)
+    a = img.astype(np.float64)
+    sm, df = np.array([1, 2, 1.0]), np.array([-1, 0, 1.0])
+    dx = ndimage.correlate(a, np.outer(sm, df), mode="mirror") / 3060.0
+    dy = ndimage.correlate(a, np.outer(df, sm), mode="mirror") / 3060.0
+    box = lambda m: ndimage.correlate(m, np.ones((3, 3)), mode="mirror")
+    xx, xy, yy = box(dx * dx), box(dx * dy), box(dy * dy)
+    ref = (xx * 0.5 + yy * 0.5) - np.sqrt((xx * 0.5 - yy * 0.5) ** 2 + xy * xy)
+    c64 = T.gftt(img, maxc, 0.01, md, eig=ref)
+    c32 = oracle.goodFeaturesToTrack(img, maxc, 0.01, md, nthreads=4)
+    assert c64.shape == c32.shape and np.array_equal(c64, c32)
+
+
 def test_gftt_candidate_rule_pinned_by_scipy_ndimage():
     """goodFeaturesToTrack with minDistance 0 and no corner limit returns every candidate: pixels above
     qualityLevel * max that equal their 3x3 maximum (grey dilation), image border excluded, strongest first with
